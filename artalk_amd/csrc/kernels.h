@@ -1,0 +1,115 @@
+// Host-side launch API of the gfx950 kernels of the ARTalk audio->motion path.
+// Every launcher enqueues on the given stream and returns immediately (no sync, no allocation),
+// so a sequence of them can be captured into a hipGraph.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cstdint>
+
+namespace artalk {
+
+// row(m) = (m / rpb) * bstride + off + (m % rpb).  Identity when rpb == INT_MAX.
+// Lets one GEMM read/write compact [B*L] rows and per-clip strided storage (KV cache, AdaLN table).
+struct RowMap {
+    int rpb;
+    int bstride;
+    int off;
+};
+static inline RowMap rowmap_identity() { return RowMap{INT_MAX, 0, 0}; }
+static inline RowMap rowmap(int rows_per_batch, int batch_stride_rows, int row_off) {
+    return RowMap{rows_per_batch, batch_stride_rows, row_off};
+}
+
+enum Act { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_TANH = 2, ACT_LEAKY02 = 3 };
+
+// C[cmap(m), n] = R[cmap(m), n] + gate[gmap(m), n] * act(sum_k A[m,k] * W[n,k] + bias[n])
+// A is [M,K] (row stride lda), W is [N,K] row-major (torch nn.Linear layout).  K % 32 == 0.
+struct GemmArgs {
+    const float* A = nullptr; long lda = 0;
+    const float* W = nullptr; long ldw = 0;
+    const float* bias = nullptr;
+    float* C = nullptr; long ldc = 0; RowMap cmap = {INT_MAX, 0, 0};
+    const float* gate = nullptr; long ldg = 0; RowMap gmap = {INT_MAX, 0, 0};
+    const float* R = nullptr; long ldr = 0;     // residual, addressed with cmap; may alias C
+    int M = 0, N = 0, K = 0;
+    int act = ACT_NONE;
+    // grid.z batching (element strides)
+    int batch = 1; long sA = 0, sW = 0, sBias = 0, sC = 0, sR = 0;
+    // amode 1: grouped positional conv window (wav2vec2 pos_conv_embed): row m = (c, t) with
+    // t = m % pc_tstride, k = (tap, ci): A[m,k] = X[c*pc_tstride + t + tap - pc_pad, ci] if in [0,pc_T) else 0
+    int amode = 0; int pc_T = 0, pc_tstride = 0, pc_pad = 0, pc_cin = 0;
+};
+void launch_gemm(const GemmArgs& g, hipStream_t s);
+// Average kernel time helper for benches: FLOPs of one launch
+static inline double gemm_flops(const GemmArgs& g) { return 2.0 * g.M * (double)g.N * g.K * g.batch; }
+
+// LayerNorm over the last dim D of M rows, one wavefront per row.
+//   y = LN(x) [* w + b]  [-> * (1 + scale[mmap(m)]) + shift[mmap(m)]]  [-> act]
+struct LnArgs {
+    const float* X = nullptr; long ldx = 0;
+    float* Y = nullptr; long ldy = 0;
+    const float* w = nullptr; const float* b = nullptr;          // affine (nullable)
+    const float* scale = nullptr; const float* shift = nullptr;  // AdaLN modulation (nullable), row stride ldm
+    long ldm = 0; RowMap mmap = {INT_MAX, 0, 0};
+    int M = 0, D = 0; float eps = 1e-5f; int act = ACT_NONE;
+};
+void launch_layernorm(const LnArgs& a, hipStream_t s);
+
+// softmax(scale * Q K^T [+mask]) V, fp32 MFMA, online softmax over 64-key blocks staged in LDS.
+struct AttnArgs {
+    const float* Q = nullptr; long ldq = 0, q_bstride = 0;
+    const float* K = nullptr; long ldk = 0, k_bstride = 0;
+    const float* V = nullptr; long ldv = 0, v_bstride = 0;
+    float* O = nullptr; long ldo = 0, o_bstride = 0;
+    int B = 0, H = 0, HD = 64, Lq = 0, Lk = 0;
+    float scale = 1.f;
+    int l2norm = 0; const float* qscale = nullptr;   // AR: q,k L2-normalised, q *= qscale[h]
+    int split_q = 0, split_k = 0;                    // queries < split_q see keys < split_k only (VAE mask)
+};
+void launch_attention(const AttnArgs& a, hipStream_t s);
+
+// ---- wav2vec2 front-end ----
+// per-chunk mean / unbiased std, writes (x-mean)/(std+1e-6); chunk c is read at audio + src_off[c]
+void launch_audio_normalize(const float* audio, const long* src_off, float* xnorm, int n_chunks, int n, hipStream_t s);
+// conv0 (Cin=1,k=10,s=5) + bias + LN(512, affine) + GELU(erf): xnorm [C, n] -> Y rows c*row_stride + t, t < T
+void launch_conv0(const float* xnorm, int n, const float* w /*[512,10]*/, const float* bias, const float* lnw,
+                  const float* lnb, float* Y, int n_chunks, int T, int row_stride, hipStream_t s);
+// multi-scale adaptive average pooling 199 -> {1,5,25,50,100} followed by SiLU: X rows c*x_tstride + t -> Y rows c*181 + tok
+void launch_pool_silu(const float* X, int x_tstride, int T, float* Y, int n_chunks, const int* patch_nums, int n_lvls,
+                      int D, hipStream_t s);
+
+// ---- AR / VAE glue ----
+struct MsTables;   // device-resident interpolation tables (built once, bsq.hip)
+// logits [B*pn, 64] -> bits of level p (written into bits[b, off..off+pn, 32]); fhat[b] += up(h_p) (p < 4)
+void launch_ar_bits(const float* logits, uint8_t* bits, float* fhat, int B, int level, hipStream_t s);
+// x_next[b*pn' + i, :] = We * area(fhat[b] -> pn')[i] + be + lvlpos[off' + i]   (input tokens of level p+1)
+void launch_ar_next_embed(const float* fhat, const float* We, const float* be, const float* lvlpos, float* x,
+                          int B, int next_level, hipStream_t s);
+// x0[b, :] = style_cond[b] + lvlpos[0]; also zeroes fhat
+void launch_ar_begin(const float* style_cond, const float* lvlpos, float* x0, float* fhat, int B, hipStream_t s);
+// decoder input rows [b*200 + t]: t<100: prev_fdec[b,t] + dpos[t]; t>=100: fhat[b,t-100] + h(bits level 4)[t-100] + dpos[t]
+void launch_dec_input(const float* prev_fdec, const float* fhat, const uint8_t* bits, const float* dpos, float* X,
+                      int B, hipStream_t s);
+// motion = dec*std+mean (2nd half rows) -> out[b, chunk*100 + t, :106]; enc_in = (motion-mean)/std + epos[t] -> E [B*100,128] (cols>=106 zero)
+void launch_dec_finish(const float* dec /*[B*200,106]*/, const float* mean, const float* stdv, const float* epos,
+                       float* out, long out_bstride, int chunk, float* E, int B, hipStream_t s);
+// zero motion encoder input (initial history): E[b*100+t] = (0-mean)/std + epos[t]
+void launch_enc_input_zero(const float* mean, const float* stdv, const float* epos, float* E, int B, hipStream_t s);
+// multi-scale BSQ of enc_out [B*100,32] -> hist bits [B,181,32], prev_fdec [B,100,32], ms feats [B,180,32]
+void launch_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fdec, float* msfeat, int B, hipStream_t s);
+// prev_in[b*181 + 0] = style_cond[b] + ppos[0]; prev_in[b*181 + 1 + i] = We*msfeat[b,i] + be + ppos[1+i]
+void launch_prev_embed(const float* style_cond, const float* msfeat, const float* We, const float* be,
+                       const float* ppos, float* prev_in, int B, hipStream_t s);
+// style: X[b*50+t, 0:128] = (m - mean)/std (cols >= 106 zero)
+void launch_style_input(const float* motion, const float* mean, const float* stdv, float* X, int B, hipStream_t s);
+// style_cond[b] = has_style[b] ? 1.1*(Ws*mean_t(feat[b]) + bs) - 0.1*null : null
+void launch_style_finish(const float* feat /*[B*50,128]*/, const float* Ws, const float* bs, const float* null_cond,
+                         const uint8_t* has_style, float* style_cond, int B, hipStream_t s);
+// y[m, :] = x[m, :] + v[:]   (broadcast add of one row; used for the style PE quirk)
+void launch_add_row(float* X, const float* v, int M, int D, hipStream_t s);
+// Savitzky-Golay post filter of reference inference.py:89-95 on device: in [T,106] -> out [T,106]
+void launch_savgol(const float* in, float* out, int T, int D, hipStream_t s);
+
+void init_ms_tables();   // uploads the (tiny) interpolation tables to __constant__ memory; idempotent
+
+}  // namespace artalk

@@ -1,0 +1,150 @@
+#!/usr/bin/env python
+"""Generate ``tests/golden/*.npz`` by running the REFERENCE itself (build container only).
+
+Imports ``BitwiseARModel`` from ``/root/reference`` (SURVEY.md Appendix A recipe: stub the absent,
+unused ``torchvision``/``torchaudio`` imports and replace the by-name hub fetch of the XLS-R config
+at ``app/models.py:25`` with the local JSON), loads the deterministic synthetic weights with
+``strict=True`` and records, per case: the FLAME codes, the per-chunk bits, the history bits, the
+decision margins, a slice of the wav2vec2 features and the Savitzky-Golay-smoothed engine output.
+
+This script never runs on the GPU box (``/root/reference`` does not exist there); only its small
+outputs are committed.  Usage:  python oracle/make_golden.py [--cases tiny,full] [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from artalk_amd.config import ARTalkConfig            # noqa: E402
+from artalk_amd.synth import synth_audio, synth_style  # noqa: E402
+from artalk_amd.weights import generate_state_dict, fingerprint, DEFAULT_SEED  # noqa: E402
+
+REFERENCE = "/root/reference"
+
+# (case name, config, audio seed, seconds, with style)
+CASES = [
+    ("tiny_4s_s0", "tiny", 0, 4.0, False),
+    ("tiny_10s_s1_style", "tiny", 1, 10.0, True),
+    ("tiny_6p3s_s2", "tiny", 2, 6.3, False),          # ragged: 158 frames, last chunk zero padded
+    ("full_10s_s0", "full", 0, 10.0, False),
+    ("full_10s_s1_style", "full", 1, 10.0, True),
+    ("full_4s_s2", "full", 2, 4.0, False),
+    ("full_5p5s_s3_style", "full", 3, 5.5, True),
+]
+
+
+def load_reference_model(cfg: ARTalkConfig, sd):
+    import transformers  # noqa: F401  (must precede the stubs: it probes torchvision.__spec__)
+    from transformers import Wav2Vec2Config as HFConfig
+    for name in ("torchvision", "torchaudio"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.dont_write_bytecode = True
+    if REFERENCE not in sys.path:
+        sys.path.insert(0, REFERENCE)
+    import app.models as M
+
+    w2v = dict(cfg.w2v)
+
+    class LocalCfg:
+        @staticmethod
+        def from_pretrained(name, *a, **k):
+            return HFConfig(**w2v)
+
+    M.Wav2Vec2Config = LocalCfg
+    model = M.BitwiseARModel(cfg.reference_dict()).eval()
+    model.load_state_dict(sd, strict=True)
+    return model
+
+
+def run_case(model, sd, seed, seconds, with_style):
+    audio = torch.from_numpy(synth_audio(seed, seconds))[None]
+    style = None
+    if with_style:
+        style = torch.from_numpy(synth_style(seed, sd["basic_vae.motion_mean"].numpy(), sd["basic_vae.motion_std"].numpy()))[None]
+    rec = dict(logits=[], quant_bits=[], bsq_in=[], w2v=[])
+    hooks = [
+        model.logits_head.register_forward_hook(lambda m, i, o: rec["logits"].append(o.detach().clone())),
+        model.basic_vae.quantize.register_forward_hook(lambda m, i, o: rec["quant_bits"].append(o[1].detach().clone())),
+        model.basic_vae.quantize.bsq_quant.register_forward_hook(lambda m, i, o: rec["bsq_in"].append(i[0].detach().clone())),
+        model.audio_encoder.register_forward_hook(lambda m, i, o: rec["w2v"].append(o.detach().clone())),
+    ]
+    t0 = time.time()
+    with torch.no_grad():
+        out = model.inference({"audio": audio, "style_motion": style})[0]
+    dt = time.time() - t0
+    for h in hooks:
+        h.remove()
+    n_chunks = len(rec["w2v"])
+    assert len(rec["logits"]) == 5 * n_chunks and len(rec["quant_bits"]) == n_chunks + 1
+    last = rec["logits"][4::5]                                     # last scale step of each chunk: (1,181,64)
+    pairs = torch.stack([l.view(181, 32, 2) for l in last])       # (chunks,181,32,2)
+    bits = pairs.argmax(-1).to(torch.uint8)
+    logit_margin = (pairs[..., 0] - pairs[..., 1]).abs()
+    hist_bits = torch.stack([b[0] for b in rec["quant_bits"]]).to(torch.uint8)   # (chunks+1,181,32)
+    zs = [torch.nn.functional.normalize(x[0], dim=-1).abs() for x in rec["bsq_in"]]   # 5 per quantize call
+    hist_margin = torch.stack([torch.cat(zs[5 * i:5 * i + 5], dim=0) for i in range(n_chunks + 1)])
+    w2v = torch.stack([x[0] for x in rec["w2v"]])                 # (chunks,199,1024)
+    # engine-level post-processing, reference inference.py:52-56,89-95
+    from scipy.signal import savgol_filter
+    m = out.numpy()
+    sm = savgol_filter(m, window_length=5, polyorder=2, axis=0)
+    sm[..., 100:103] = savgol_filter(m[..., 100:103], window_length=9, polyorder=3, axis=0)
+    eng = sm[:750].copy()
+    eng[..., 104:] *= 0.0
+    return dict(
+        out=out.numpy().astype(np.float32),
+        engine_out=eng.astype(np.float32),
+        bits=np.packbits(bits.numpy(), axis=-1),
+        hist_bits=np.packbits(hist_bits.numpy(), axis=-1),
+        logit_margin=logit_margin.numpy().astype(np.float16),
+        hist_margin=hist_margin.numpy().astype(np.float16),
+        w2v_slice=w2v[:, :, :16].numpy().astype(np.float32),
+        w2v_abs_mean=np.float64(w2v.abs().double().mean().item()),
+        w2v_sum=np.float64(w2v.double().sum().item()),
+        seed=np.int64(seed), seconds=np.float64(seconds), with_style=np.bool_(with_style),
+        ref_seconds=np.float64(dt),
+    )
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", default="tiny,full")
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.manual_seed(0)
+    for cfg_name in args.cases.split(","):
+        cfg = ARTalkConfig.by_name(cfg_name)
+        t0 = time.time()
+        sd = generate_state_dict(cfg, DEFAULT_SEED)
+        print(f"[{cfg_name}] weights generated in {time.time() - t0:.1f}s", flush=True)
+        t0 = time.time()
+        model = load_reference_model(cfg, sd)
+        print(f"[{cfg_name}] reference constructed + strict load in {time.time() - t0:.1f}s", flush=True)
+        fp = fingerprint(sd)
+        for name, c, seed, seconds, with_style in CASES:
+            if c != cfg_name:
+                continue
+            g = run_case(model, sd, seed, seconds, with_style)
+            g["weights_seed"] = np.int64(DEFAULT_SEED)
+            g["weights_fingerprint_keys"] = np.array(list(fp.keys()))
+            g["weights_fingerprint"] = np.array([fp[k] for k in fp], dtype=np.float64)
+            g["versions"] = np.array([torch.__version__, np.__version__])
+            path = os.path.join(args.out, name + ".npz")
+            np.savez_compressed(path, **g)
+            print(f"  {name}: frames={g['out'].shape[0]} ref_time={float(g['ref_seconds']):.2f}s "
+                  f"min logit margin={g['logit_margin'].min():.2e} min hist margin={g['hist_margin'].min():.2e} "
+                  f"-> {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+        del model, sd
+
+
+if __name__ == "__main__":
+    main()
