@@ -1,0 +1,134 @@
+"""ctypes binding of ``libartalk_hip.so`` (C ABI declared in ``include/artalk_hip.h``).
+
+The library is the product path: if it is missing this module raises, there is no CPU fallback.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` (or ``make -C artalk_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .config import ARTalkConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libartalk_hip.so")
+
+OK, EINVAL, EKEY, EMISSING, EHIP, ESTATE, ECAPACITY = 0, -1, -2, -3, -4, -5, -6
+DTYPE_F32, DTYPE_I64 = 0, 1
+
+# every symbol include/artalk_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "artalk_create", "artalk_destroy", "artalk_last_error", "artalk_set_tensor", "artalk_finalize_weights",
+    "artalk_reserve", "artalk_workspace_bytes", "artalk_weight_bytes", "artalk_infer", "artalk_savgol",
+    "artalk_set_profiling", "artalk_get_profile", "artalk_set_graphs",
+    "artalk_op_gemm", "artalk_op_layernorm", "artalk_op_attention", "artalk_op_w2v_front", "artalk_op_pool_silu",
+    "artalk_op_bsq_history",
+]
+
+
+class ArtalkConfigStruct(C.Structure):
+    _fields_ = [
+        ("ar_depth", C.c_int32), ("ar_heads", C.c_int32),
+        ("vae_depth", C.c_int32), ("vae_heads", C.c_int32), ("vae_hidden", C.c_int32),
+        ("code_dim", C.c_int32), ("motion_dim", C.c_int32),
+        ("n_levels", C.c_int32), ("patch_nums", C.c_int32 * 8),
+        ("w2v_layers", C.c_int32), ("w2v_hidden", C.c_int32), ("w2v_heads", C.c_int32), ("w2v_ffn", C.c_int32),
+        ("w2v_n_conv", C.c_int32), ("w2v_conv_kernel", C.c_int32 * 8), ("w2v_conv_stride", C.c_int32 * 8),
+        ("w2v_conv_dim", C.c_int32),
+        ("w2v_pos_kernel", C.c_int32), ("w2v_pos_groups", C.c_int32),
+        ("w2v_ln_eps", C.c_float),
+        ("style_dim", C.c_int32), ("style_heads", C.c_int32), ("style_layers", C.c_int32), ("style_ffn", C.c_int32),
+        ("style_len", C.c_int32),
+    ]
+
+
+def config_struct(cfg: ARTalkConfig) -> ArtalkConfigStruct:
+    w = cfg.w2v
+    if w.get("feat_extract_norm", "layer") != "layer" or not w.get("do_stable_layer_norm", True) or not w.get("conv_bias", True):
+        raise ValueError("only the XLS-R style wav2vec2 (layer-norm conv stack, stable layer norm, conv bias) is supported")
+    if len(set(w["conv_dim"])) != 1:
+        raise ValueError("conv_dim must be uniform")
+    s = ArtalkConfigStruct()
+    s.ar_depth, s.ar_heads = cfg.ar_depth, cfg.ar_heads
+    s.vae_depth, s.vae_heads, s.vae_hidden = cfg.vae_depth, cfg.vae_heads, cfg.vae_hidden
+    s.code_dim, s.motion_dim = cfg.code_dim, cfg.motion_dim
+    s.n_levels = len(cfg.patch_nums)
+    for i, p in enumerate(cfg.patch_nums):
+        s.patch_nums[i] = p
+    s.w2v_layers, s.w2v_hidden = w["num_hidden_layers"], w["hidden_size"]
+    s.w2v_heads, s.w2v_ffn = w["num_attention_heads"], w["intermediate_size"]
+    s.w2v_n_conv = len(w["conv_kernel"])
+    for i, (k, st) in enumerate(zip(w["conv_kernel"], w["conv_stride"])):
+        s.w2v_conv_kernel[i], s.w2v_conv_stride[i] = k, st
+    s.w2v_conv_dim = w["conv_dim"][0]
+    s.w2v_pos_kernel, s.w2v_pos_groups = w["num_conv_pos_embeddings"], w["num_conv_pos_embedding_groups"]
+    s.w2v_ln_eps = w["layer_norm_eps"]
+    s.style_dim, s.style_heads, s.style_layers = cfg.style_dim, cfg.style_heads, cfg.style_layers
+    s.style_ffn, s.style_len = cfg.style_ffn, cfg.style_len
+    return s
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the shared library once and declare the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    L.artalk_create.argtypes = [i32, C.POINTER(ArtalkConfigStruct), C.POINTER(vp)]
+    L.artalk_create.restype = i32
+    L.artalk_destroy.argtypes = [vp]
+    L.artalk_destroy.restype = None
+    L.artalk_last_error.argtypes = [vp]
+    L.artalk_last_error.restype = C.c_char_p
+    L.artalk_set_tensor.argtypes = [vp, C.c_char_p, vp, i32, i32, C.POINTER(i64)]
+    L.artalk_set_tensor.restype = i32
+    L.artalk_finalize_weights.argtypes = [vp]
+    L.artalk_finalize_weights.restype = i32
+    L.artalk_reserve.argtypes = [vp, i32, i32]
+    L.artalk_reserve.restype = i32
+    L.artalk_workspace_bytes.argtypes = [vp]
+    L.artalk_workspace_bytes.restype = i64
+    L.artalk_weight_bytes.argtypes = [vp]
+    L.artalk_weight_bytes.restype = i64
+    L.artalk_infer.argtypes = [vp, vp, i64, C.POINTER(i64), i32, vp, vp, vp, i64, vp, vp, vp, vp]
+    L.artalk_infer.restype = i32
+    L.artalk_savgol.argtypes = [vp, vp, vp, i32, vp]
+    L.artalk_savgol.restype = i32
+    L.artalk_set_profiling.argtypes = [vp, i32]
+    L.artalk_set_profiling.restype = i32
+    L.artalk_get_profile.argtypes = [vp, C.POINTER(C.c_double), i32]
+    L.artalk_get_profile.restype = i32
+    L.artalk_set_graphs.argtypes = [vp, i32]
+    L.artalk_set_graphs.restype = i32
+    L.artalk_op_gemm.argtypes = [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.artalk_op_gemm.restype = i32
+    L.artalk_op_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]
+    L.artalk_op_layernorm.restype = i32
+    L.artalk_op_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, i32, vp]
+    L.artalk_op_attention.restype = i32
+    L.artalk_op_w2v_front.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.artalk_op_w2v_front.restype = i32
+    L.artalk_op_pool_silu.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.artalk_op_pool_silu.restype = i32
+    L.artalk_op_bsq_history.argtypes = [vp, vp, vp, vp, i32, vp]
+    L.artalk_op_bsq_history.restype = i32
+    _lib = L
+    return L
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

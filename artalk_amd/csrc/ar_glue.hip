@@ -1,0 +1,381 @@
+// Small kernels between the GEMMs of the AR / VAE / style stages: bit decisions, the multi-scale
+// binary-spherical-quantiser arithmetic and the embeddings around it.  All are tiny (<= 3200 floats per clip)
+// and exist so that the whole scale step stays on the device (hipGraph-capturable, no host round trip).
+//
+//   ar_bits        app/models.py:104 (pairwise argmax) + bitwise_vae.py:291-305 (f_hat recurrence, area pooling)
+//   vq_embed       app/models.py:19,100,106-107,113 (vqfeat_embed, style token, + level/position embedding)
+//   dec_input      bitwise_vae.py:105-110,280-288
+//   dec_finish     bitwise_vae.py:63-65,111-113 ; :59-61,87 for the re-encode input
+//   bsq_history    bitwise_vae.py:227-242,316-334 (MultiScaleBSQ/BSQ forward) + :269-288 (features from bits)
+//   style_*        app/modules/style_encoder.py:26-38,58-60 ; app/models.py:67-73
+//   savgol         inference.py:89-95 (scipy.signal.savgol_filter, mode='interp')
+#include "common.h"
+#include <cmath>
+#include <mutex>
+
+namespace artalk {
+
+constexpr int T100 = 100;   // frames per chunk = finest scale
+constexpr int CD = 32;      // code dim
+constexpr int NLV = 5;
+__constant__ int c_pn[NLV];            // 1,5,25,50,100
+__constant__ int c_off[NLV + 1];       // 0,1,6,31,81,181
+__constant__ int c_up_i0[4][T100];     // linear upsample pn[p] -> 100 (align_corners=False)
+__constant__ int c_up_i1[4][T100];
+__constant__ float c_up_w1[4][T100];
+__constant__ float c_hq;               // 1/sqrt(32)
+
+static const int h_pn[NLV] = {1, 5, 25, 50, 100};
+
+void init_ms_tables() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int off[NLV + 1] = {0};
+        for (int i = 0; i < NLV; ++i) off[i + 1] = off[i] + h_pn[i];
+        int i0[4][T100], i1[4][T100];
+        float w1[4][T100];
+        for (int p = 0; p < 4; ++p) {
+            const int in = h_pn[p];
+            const float scale = (float)in / (float)T100;     // ATen area_pixel_compute_scale
+            for (int t = 0; t < T100; ++t) {
+                float src = scale * ((float)t + 0.5f) - 0.5f;   // area_pixel_compute_source_index
+                if (src < 0.f) src = 0.f;
+                const int a = (int)src;
+                i0[p][t] = a;
+                i1[p][t] = a + ((a < in - 1) ? 1 : 0);
+                w1[p][t] = src - (float)a;
+            }
+        }
+        const float hq = 1.0f / (float)std::sqrt(32.0);
+        hipMemcpyToSymbol(HIP_SYMBOL(c_pn), h_pn, sizeof(h_pn));
+        hipMemcpyToSymbol(HIP_SYMBOL(c_off), off, sizeof(off));
+        hipMemcpyToSymbol(HIP_SYMBOL(c_up_i0), i0, sizeof(i0));
+        hipMemcpyToSymbol(HIP_SYMBOL(c_up_i1), i1, sizeof(i1));
+        hipMemcpyToSymbol(HIP_SYMBOL(c_up_w1), w1, sizeof(w1));
+        hipMemcpyToSymbol(HIP_SYMBOL(c_hq), &hq, sizeof(hq));
+    });
+}
+
+__device__ __forceinline__ float up_lin(const float* src /*[pn][32] in LDS*/, int p, int t, int c) {
+    const float w1 = c_up_w1[p][t], w0 = 1.0f - w1;
+    return w0 * src[c_up_i0[p][t] * CD + c] + w1 * src[c_up_i1[p][t] * CD + c];
+}
+// adaptive average pooling of f[100][32] to pn bins (100 % pn == 0 for pn in {1,5,25,50,100})
+__device__ __forceinline__ float area_pool(const float* f, int pn, int i, int c) {
+    const int w = T100 / pn;
+    float s = 0.f;
+    for (int t = i * w; t < (i + 1) * w; ++t) s += f[t * CD + c];
+    return s / (float)w;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ar_begin_kernel(const float* __restrict__ style_cond, const float* __restrict__ lvlpos,
+                                                       float* __restrict__ x0, float* __restrict__ fhat, int E) {
+    const int b = blockIdx.x;
+    for (int n = threadIdx.x; n < E; n += 256) x0[(long)b * E + n] = style_cond[(long)b * E + n] + lvlpos[n];
+    for (int i = threadIdx.x; i < T100 * CD; i += 256) fhat[(long)b * T100 * CD + i] = 0.f;
+}
+void launch_ar_begin(const float* style_cond, const float* lvlpos, float* x0, float* fhat, int B, hipStream_t s) {
+    hipLaunchKernelGGL(ar_begin_kernel, dim3(B), dim3(256), 0, s, style_cond, lvlpos, x0, fhat, 768);
+}
+
+// ------------------------------------------------------------------------------------------------
+// level p: logits rows b*pn+i -> bits; f_hat += up(h_p); nextfeat[b, i', :] = area(f_hat -> pn[p+1])
+__global__ __launch_bounds__(256) void ar_bits_kernel(const float* __restrict__ logits, uint8_t* __restrict__ bits,
+                                                      float* __restrict__ fhat, float* __restrict__ nextfeat, int p) {
+    __shared__ float hs[T100 * CD];
+    __shared__ float fs[T100 * CD];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int pn = c_pn[p], off = c_off[p];
+    for (int idx = tid; idx < pn * CD; idx += 256) {
+        const int i = idx / CD, c = idx % CD;
+        const float* l = logits + ((long)b * pn + i) * (2 * CD) + 2 * c;
+        const int bit = l[1] > l[0];                       // argmax over the pair, ties -> 0
+        bits[((long)b * 181 + off + i) * CD + c] = (uint8_t)bit;
+        hs[idx] = bit ? c_hq : -c_hq;
+    }
+    if (p >= NLV - 1) return;
+    __syncthreads();
+    float* fg = fhat + (long)b * T100 * CD;
+    for (int idx = tid; idx < T100 * CD; idx += 256) {
+        const int t = idx / CD, c = idx % CD;
+        const float v = fg[idx] + up_lin(hs, p, t, c);
+        fg[idx] = v;
+        fs[idx] = v;
+    }
+    __syncthreads();
+    const int pn2 = c_pn[p + 1];
+    for (int idx = tid; idx < pn2 * CD; idx += 256)
+        nextfeat[(long)b * pn2 * CD + idx] = area_pool(fs, pn2, idx / CD, idx % CD);
+}
+void launch_ar_bits_next(const float* logits, uint8_t* bits, float* fhat, float* nextfeat, int B, int level, hipStream_t s) {
+    hipLaunchKernelGGL(ar_bits_kernel, dim3(B), dim3(256), 0, s, logits, bits, fhat, nextfeat, level);
+}
+
+// ------------------------------------------------------------------------------------------------
+// X[b*xrows + xoff + i, :] = We * feat[b, i, :] + be + pos[i, :]      for i < n          (grid.x = i)
+// X[b*xrows + 0, :]        = style_cond[b, :] + pos0[:]                for blockIdx.x == n (only if style_cond)
+__global__ __launch_bounds__(256) void vq_embed_kernel(const float* __restrict__ feat, int n, const float* __restrict__ We,
+                                                       const float* __restrict__ be, const float* __restrict__ pos,
+                                                       float* __restrict__ X, int xrows, int xoff,
+                                                       const float* __restrict__ style_cond, const float* __restrict__ pos0, int E) {
+    __shared__ float f[CD];
+    const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (i == n) {
+        for (int e = tid; e < E; e += 256) X[((long)b * xrows) * E + e] = style_cond[(long)b * E + e] + pos0[e];
+        return;
+    }
+    if (tid < CD) f[tid] = feat[((long)b * n + i) * CD + tid];
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) {
+        const float* w = We + (long)e * CD;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < CD; ++c) acc = fmaf(w[c], f[c], acc);
+        X[((long)b * xrows + xoff + i) * E + e] = (acc + be[e]) + pos[(long)i * E + e];
+    }
+}
+void launch_vq_embed(const float* feat, int n, const float* We, const float* be, const float* pos, float* X, int xrows,
+                     int xoff, const float* style_cond, const float* pos0, int B, hipStream_t s) {
+    hipLaunchKernelGGL(vq_embed_kernel, dim3(n + (style_cond ? 1 : 0), B), dim3(256), 0, s, feat, n, We, be, pos, X, xrows, xoff,
+                       style_cond, pos0, 768);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dec_input_kernel(const float* __restrict__ prev_fdec, const float* __restrict__ fhat,
+                                                        const uint8_t* __restrict__ bits, const float* __restrict__ dpos,
+                                                        float* __restrict__ X) {
+    const int b = blockIdx.x;
+    for (int idx = threadIdx.x; idx < 2 * T100 * CD; idx += 256) {
+        const int t = idx / CD, c = idx % CD;
+        float v;
+        if (t < T100) {
+            v = prev_fdec[(long)b * T100 * CD + idx];
+        } else {
+            const int tt = t - T100;
+            const float h = bits[((long)b * 181 + 81 + tt) * CD + c] ? c_hq : -c_hq;
+            v = fhat[(long)b * T100 * CD + tt * CD + c] + h;
+        }
+        X[(long)b * 2 * T100 * CD + idx] = v + dpos[idx];
+    }
+}
+void launch_dec_input(const float* prev_fdec, const float* fhat, const uint8_t* bits, const float* dpos, float* X, int B,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(dec_input_kernel, dim3(B), dim3(256), 0, s, prev_fdec, fhat, bits, dpos, X);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dec_finish_kernel(const float* __restrict__ dec, const float* __restrict__ mean,
+                                                         const float* __restrict__ stdv, const float* __restrict__ epos,
+                                                         float* __restrict__ out, long out_bstride, int chunk,
+                                                         float* __restrict__ E, int MD, int EK) {
+    const int b = blockIdx.x;
+    for (int idx = threadIdx.x; idx < T100 * EK; idx += 256) {
+        const int t = idx / EK, j = idx % EK;
+        float e = 0.f;
+        if (j < MD) {
+            const float d = dec[((long)b * 2 * T100 + T100 + t) * MD + j];
+            const float m = d * stdv[j] + mean[j];
+            out[(long)b * out_bstride + ((long)chunk * T100 + t) * MD + j] = m;
+            e = (m - mean[j]) / stdv[j] + epos[t * MD + j];
+        }
+        E[((long)b * T100 + t) * EK + j] = e;
+    }
+}
+void launch_dec_finish(const float* dec, const float* mean, const float* stdv, const float* epos, float* out,
+                       long out_bstride, int chunk, float* E, int B, hipStream_t s) {
+    hipLaunchKernelGGL(dec_finish_kernel, dim3(B), dim3(256), 0, s, dec, mean, stdv, epos, out, out_bstride, chunk, E, 106, 128);
+}
+
+__global__ __launch_bounds__(256) void enc_input_zero_kernel(const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                             const float* __restrict__ epos, float* __restrict__ E, int MD, int EK) {
+    const int b = blockIdx.x;
+    for (int idx = threadIdx.x; idx < T100 * EK; idx += 256) {
+        const int t = idx / EK, j = idx % EK;
+        E[((long)b * T100 + t) * EK + j] = (j < MD) ? ((0.f - mean[j]) / stdv[j] + epos[t * MD + j]) : 0.f;
+    }
+}
+void launch_enc_input_zero(const float* mean, const float* stdv, const float* epos, float* E, int B, hipStream_t s) {
+    hipLaunchKernelGGL(enc_input_zero_kernel, dim3(B), dim3(256), 0, s, mean, stdv, epos, E, 106, 128);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One workgroup per clip.  Sequential over the 5 scales (each needs the residual left by the previous one).
+__global__ __launch_bounds__(256) void bsq_history_kernel(const float* __restrict__ enc_out, uint8_t* __restrict__ hist_bits,
+                                                          float* __restrict__ prev_fdec, float* __restrict__ msfeat) {
+    __shared__ float resid[T100 * CD];
+    __shared__ float fms[T100 * CD];     // sum of up(h_p), the feature recurrence from bits
+    __shared__ float qs[T100 * CD];      // quantised values q = z + (zhat - z) of this scale
+    __shared__ float hs[T100 * CD];      // +-1/sqrt(32) from the bits of this scale
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int idx = tid; idx < T100 * CD; idx += 256) {
+        resid[idx] = enc_out[(long)b * T100 * CD + idx];
+        fms[idx] = 0.f;
+    }
+    __syncthreads();
+    int msoff = 0;
+    for (int p = 0; p < NLV; ++p) {
+        const int pn = c_pn[p], off = c_off[p];
+        // all 256 threads run the loop body the same number of times (3200 % 256 != 0 -> guard inside, shuffles outside)
+        for (int base = 0; base < pn * CD; base += 256) {
+            const int idx = base + tid;
+            const bool ok = idx < pn * CD;
+            const int i = ok ? idx / CD : 0, c = idx % CD;
+            float x = 0.f;
+            if (ok) x = (pn == T100) ? resid[idx] : area_pool(resid, pn, i, c);
+            float ss = x * x;                      // 32 consecutive lanes = one token
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            const float z = x / fmaxf(sqrtf(ss), 1e-12f);
+            const float zhat = (z > 0.f) ? c_hq : -c_hq;
+            const float q = z + (zhat - z);
+            const int bit = q > 0.f;
+            if (ok) {
+                qs[idx] = q;
+                hs[idx] = bit ? c_hq : -c_hq;
+                hist_bits[((long)b * 181 + off + i) * CD + c] = (uint8_t)bit;
+            }
+        }
+        __syncthreads();
+        if (p < NLV - 1) {
+            for (int idx = tid; idx < T100 * CD; idx += 256) {
+                const int t = idx / CD, c = idx % CD;
+                resid[idx] -= up_lin(qs, p, t, c);
+                fms[idx] += up_lin(hs, p, t, c);
+            }
+            __syncthreads();
+            const int pn2 = c_pn[p + 1];
+            for (int idx = tid; idx < pn2 * CD; idx += 256)
+                msfeat[((long)b * 180 + msoff) * CD + idx] = area_pool(fms, pn2, idx / CD, idx % CD);
+            msoff += pn2;
+        } else {
+            for (int idx = tid; idx < T100 * CD; idx += 256) prev_fdec[(long)b * T100 * CD + idx] = fms[idx] + hs[idx];
+        }
+        __syncthreads();
+    }
+}
+void launch_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fdec, float* msfeat, int B, hipStream_t s) {
+    hipLaunchKernelGGL(bsq_history_kernel, dim3(B), dim3(256), 0, s, enc_out, hist_bits, prev_fdec, msfeat);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void style_input_kernel(const float* __restrict__ motion, const float* __restrict__ mean,
+                                                          const float* __restrict__ stdv, float* __restrict__ X, int rows, int MD, int EK) {
+    const long n = (long)rows * EK;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const long row = idx / EK; const int j = idx % EK;
+        X[idx] = (j < MD) ? (motion[row * MD + j] - mean[j]) / stdv[j] : 0.f;
+    }
+}
+void launch_style_input(const float* motion, const float* mean, const float* stdv, float* X, int B, hipStream_t s) {
+    const int rows = B * 50;
+    hipLaunchKernelGGL(style_input_kernel, dim3((rows * 128 + 255) / 256), dim3(256), 0, s, motion, mean, stdv, X, rows, 106, 128);
+}
+
+__global__ __launch_bounds__(256) void add_row_kernel(float* __restrict__ X, const float* __restrict__ v, long n, int D) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) X[idx] += v[idx % D];
+}
+void launch_add_row(float* X, const float* v, int M, int D, hipStream_t s) {
+    const long n = (long)M * D;
+    hipLaunchKernelGGL(add_row_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, v, n, D);
+}
+
+__global__ __launch_bounds__(256) void style_finish_kernel(const float* __restrict__ feat, const float* __restrict__ Ws,
+                                                           const float* __restrict__ bs, const float* __restrict__ null_cond,
+                                                           const uint8_t* __restrict__ has_style, float* __restrict__ style_cond,
+                                                           int L, int S, int E) {
+    __shared__ float m[128];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const bool has = has_style ? has_style[b] != 0 : false;
+    if (!has) {
+        for (int e = tid; e < E; e += 256) style_cond[(long)b * E + e] = null_cond[e];
+        return;
+    }
+    if (tid < S) {
+        float s = 0.f;
+        for (int t = 0; t < L; ++t) s += feat[((long)b * L + t) * S + tid];
+        m[tid] = s / (float)L;
+    }
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) {
+        const float* w = Ws + (long)e * S;
+        float acc = 0.f;
+        for (int c = 0; c < S; ++c) acc = fmaf(w[c], m[c], acc);
+        style_cond[(long)b * E + e] = (acc + bs[e]) * 1.1f - null_cond[e] * 0.1f;
+    }
+}
+void launch_style_finish(const float* feat, const float* Ws, const float* bs, const float* null_cond,
+                         const uint8_t* has_style, float* style_cond, int B, hipStream_t s) {
+    hipLaunchKernelGGL(style_finish_kernel, dim3(B), dim3(256), 0, s, feat, Ws, bs, null_cond, has_style, style_cond, 50, 128, 768);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Savitzky-Golay (5,2) on all dims, (9,3) on dims 100:103 of the unsmoothed signal; scipy mode='interp':
+// FIR in the interior, least-squares polynomial of the first/last window evaluated at the edge samples.
+// Coefficients are computed on the host in double; the kernel accumulates in double and rounds once,
+// like scipy (float64 coefficients, float32 data).
+struct SavgolCoef {
+    double fir5[5], edge5[2][5];     // edge rows: output i (0,1) from first 5 samples; mirrored for the tail
+    double fir9[9], edge9[4][9];
+};
+
+static void polyfit_edge(int window, int order, int n_edge, double* out /*[n_edge][window]*/, double* fir /*[window]*/) {
+    // Least squares: y ~ sum_k a_k x^k over x = 0..window-1.  H = A (A^T A)^-1 A^T; row i of H evaluates the fit at x=i.
+    const int m = order + 1;
+    double ata[16] = {0}, inv[16];
+    for (int r = 0; r < m; ++r)
+        for (int c = 0; c < m; ++c) {
+            double s = 0;
+            for (int x = 0; x < window; ++x) s += std::pow((double)x, r + c);
+            ata[r * m + c] = s;
+        }
+    // Gauss-Jordan inverse (m <= 4)
+    double aug[4][8];
+    for (int r = 0; r < m; ++r)
+        for (int c = 0; c < 2 * m; ++c) aug[r][c] = c < m ? ata[r * m + c] : (c - m == r ? 1.0 : 0.0);
+    for (int col = 0; col < m; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < m; ++r) if (std::fabs(aug[r][col]) > std::fabs(aug[piv][col])) piv = r;
+        for (int c = 0; c < 2 * m; ++c) std::swap(aug[col][c], aug[piv][c]);
+        const double d = aug[col][col];
+        for (int c = 0; c < 2 * m; ++c) aug[col][c] /= d;
+        for (int r = 0; r < m; ++r)
+            if (r != col) { const double f = aug[r][col]; for (int c = 0; c < 2 * m; ++c) aug[r][c] -= f * aug[col][c]; }
+    }
+    for (int r = 0; r < m; ++r) for (int c = 0; c < m; ++c) inv[r * m + c] = aug[r][m + c];
+    auto H = [&](int i, int j) {
+        double s = 0;
+        for (int r = 0; r < m; ++r) for (int c = 0; c < m; ++c) s += std::pow((double)i, r) * inv[r * m + c] * std::pow((double)j, c);
+        return s;
+    };
+    for (int i = 0; i < n_edge; ++i) for (int j = 0; j < window; ++j) out[i * window + j] = H(i, j);
+    for (int j = 0; j < window; ++j) fir[j] = H(window / 2, j);
+}
+
+__global__ __launch_bounds__(128) void savgol_kernel(const float* __restrict__ in, float* __restrict__ out, int T, int D, SavgolCoef k) {
+    const int t = blockIdx.x, d = threadIdx.x;
+    if (d >= D) return;
+    double acc = 0.0;
+    if (d >= 100 && d < 103) {
+        if (t < 4) { for (int j = 0; j < 9; ++j) acc += k.edge9[t][j] * (double)in[(long)j * D + d]; }
+        else if (t >= T - 4) { const int i = T - 1 - t; for (int j = 0; j < 9; ++j) acc += k.edge9[i][j] * (double)in[(long)(T - 1 - j) * D + d]; }
+        else { for (int j = 0; j < 9; ++j) acc += k.fir9[j] * (double)in[(long)(t - 4 + j) * D + d]; }
+    } else {
+        if (t < 2) { for (int j = 0; j < 5; ++j) acc += k.edge5[t][j] * (double)in[(long)j * D + d]; }
+        else if (t >= T - 2) { const int i = T - 1 - t; for (int j = 0; j < 5; ++j) acc += k.edge5[i][j] * (double)in[(long)(T - 1 - j) * D + d]; }
+        else { for (int j = 0; j < 5; ++j) acc += k.fir5[j] * (double)in[(long)(t - 2 + j) * D + d]; }
+    }
+    out[(long)t * D + d] = (float)acc;
+}
+void launch_savgol(const float* in, float* out, int T, int D, hipStream_t s) {
+    static SavgolCoef k;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        polyfit_edge(5, 2, 2, &k.edge5[0][0], k.fir5);
+        polyfit_edge(9, 3, 4, &k.edge9[0][0], k.fir9);
+    });
+    if (T < 9) abort();   // the Python host raises ValueError first (scipy does the same for mode='interp')
+    hipLaunchKernelGGL(savgol_kernel, dim3(T), dim3(128), 0, s, in, out, T, D, k);
+}
+
+}  // namespace artalk

@@ -1,0 +1,187 @@
+// fp32 attention on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32), used by all four attention sites:
+//   wav2vec2 encoder  hf:467-548            16 heads x 64, T=199, scale 1/8, no mask
+//   AR blocks         app/transformer.py:65-79   12 heads x 64, L2-normalised q,k, per-head learned scale, SDPA scale 1.
+//                     With the per-layer KV cache the keys present (181 history + levels <= current) are exactly the
+//                     visible set of app/models.py:123-135, so no bias tensor is needed.
+//   VAE blocks        app/modules/bitwise_vae.py:194-215  8 heads x 64, scale = 512^-0.5, mask: rows<100 see keys<100
+//   style encoder     nn.MultiheadAttention  4 heads x 32
+//
+// One workgroup = 4 wavefronts x 16 queries.  K/V blocks of 64 keys are staged in LDS (K rows padded to
+// HD+8, V rows to HD+4 floats: conflict-free for the fragment reads below) and shared by the 4 waves.
+// Each wave computes S^T = K Q^T (key on the accumulator rows, query on the lane), so that
+//  * the softmax statistics of a query are reduced over 4 registers and two cross-lane steps (xor 16, 32),
+//  * the S^T accumulator is directly the B operand of O^T += V^T P^T (guide section 3 "accumulator as next
+//    operand"): k-slot g of step j carries key 4g+j, and the V fragment is read with the same permutation.
+#include "common.h"
+
+namespace artalk {
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+    constexpr int KB = 64;
+    constexpr int KLD = HD + 8, VLD = HD + 4;
+    constexpr int NC = HD / 16;    // 16-byte chunks of a q/k row held per lane (chunk index g + 4c)
+    constexpr int NDT = HD / 16;   // 16-wide d tiles of O^T
+    constexpr int TPR = HD / 4;    // staging threads per row
+    __shared__ __attribute__((aligned(16))) float Ks[KB * KLD];
+    __shared__ __attribute__((aligned(16))) float Vs[KB * VLD];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int qblk0 = blockIdx.x * 64;
+    const int q0 = qblk0 + wave * 16;
+    const int qi = q0 + r;
+    const bool qvalid = qi < a.Lq;
+    const bool wave_active = q0 < a.Lq;
+
+    // ---- Q fragment (B operand of S^T): lane (r,g) holds Q[qi][4(g+4c)+e] ----
+    f32x4 qf[NC];
+    {
+        const float* qp = a.Q + (long)b * a.q_bstride + (long)qi * a.ldq + h * HD;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            qf[c] = qvalid ? *reinterpret_cast<const f32x4*>(qp + 4 * (g + 4 * c)) : z;
+        }
+        if (a.l2norm) {
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ss += qf[c][e] * qf[c][e];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float den = fmaxf(sqrtf(ss), 1e-12f);
+            const float mul = a.qscale[h];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qf[c][e] = (qf[c][e] / den) * mul;
+        }
+        if (a.scale != 1.0f) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qf[c][e] *= a.scale;
+        }
+    }
+    const int klim = (a.split_q > 0 && qi < a.split_q) ? a.split_k : a.Lk;   // this query sees keys < klim
+    const int qblk_last = min(qblk0 + 63, a.Lq - 1);
+    const int lk_wg = (a.split_q > 0 && qblk_last < a.split_q) ? a.split_k : a.Lk;
+
+    float m_run = -INFINITY, l_part = 0.f;
+    f32x4 ot[NDT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; ot[d] = z; }
+
+    const float* Kb = a.K + (long)b * a.k_bstride + h * HD;
+    const float* Vb = a.V + (long)b * a.v_bstride + h * HD;
+
+    for (int kb0 = 0; kb0 < lk_wg; kb0 += KB) {
+        __syncthreads();
+        // ---- stage K (optionally L2-normalised) and V rows kb0..kb0+63; rows >= Lk are zero ----
+#pragma unroll
+        for (int i = 0; i < KB * TPR / 256; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / TPR, c4 = (idx % TPR) * 4;
+            const int kr = kb0 + row;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (kr < a.Lk) {
+                kv = *reinterpret_cast<const f32x4*>(Kb + (long)kr * a.ldk + c4);
+                vv = *reinterpret_cast<const f32x4*>(Vb + (long)kr * a.ldv + c4);
+            }
+            if (a.l2norm) {
+                float ss = kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2] + kv[3] * kv[3];
+#pragma unroll
+                for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                const float den = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kv[e] = kv[e] / den;
+            }
+            *reinterpret_cast<f32x4*>(Ks + row * KLD + c4) = kv;
+            *reinterpret_cast<f32x4*>(Vs + row * VLD + c4) = vv;
+        }
+        __syncthreads();
+        if (!wave_active) continue;
+
+        // ---- S^T tiles: st[t][j] = S[key kb0+16t+4g+j][query qi] ----
+        f32x4 st[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (t * 16 + r) * KLD + 4 * (g + 4 * c));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[c][e], acc, 0, 0, 0);
+            }
+            st[t] = acc;
+        }
+        // ---- online softmax over this key block (per query = per lane column) ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kidx = kb0 + t * 16 + 4 * g + j;
+                const float sv = (kidx < klim) ? st[t][j] : -INFINITY;
+                st[t][j] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = expf(m_run - m_safe);
+        m_run = m_new;
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float p = expf(st[t][j] - m_safe);
+                st[t][j] = p;
+                ps += p;
+            }
+        l_part = l_part * alpha + ps;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) ot[d] *= alpha;
+        // ---- O^T += V^T P^T: step (t,j): k-slot g <-> key 16t+4g+j; A = V[key][16d + r], B = st[t][j] ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* vrow = Vs + (t * 16 + 4 * g + j) * VLD + r;
+#pragma unroll
+                for (int d = 0; d < NDT; ++d)
+                    ot[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[d * 16], st[t][j], ot[d], 0, 0, 0);
+            }
+    }
+    if (!wave_active) return;
+    float l = l_part;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qvalid) {
+        const float inv = 1.0f / l;
+        float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+            f32x4 o = ot[d] * inv;
+            *reinterpret_cast<f32x4*>(op + d * 16 + 4 * g) = o;   // O^T rows 4g..4g+3 of tile d = 4 consecutive d
+        }
+    }
+}
+
+void launch_attention(const AttnArgs& a, hipStream_t s) {
+    if (a.B <= 0 || a.Lq <= 0) return;
+    dim3 grid((a.Lq + 63) / 64, a.H, a.B), block(256);
+    if (a.HD == 64)
+        hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, a);
+    else if (a.HD == 32)
+        hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, a);
+    else
+        abort();
+}
+
+}  // namespace artalk

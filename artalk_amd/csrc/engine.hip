@@ -1,0 +1,944 @@
+// Model object behind the C ABI (include/artalk_hip.h): weight table in the reference's key names, derived
+// layouts, workspace, and the launch sequence of the audio->motion path.
+//
+// Execution plan (differs from the reference's loop order, app/models.py:92-114, same arithmetic per token):
+//   1. style encoder for all clips                                   (app/models.py:67-73)
+//   2. wav2vec2 for ALL 4-second chunks of ALL clips in one batched pass - chunk i of the audio does not depend on
+//      the AR state (app/models.py:93), so M = chunks*200 rows per GEMM instead of 199
+//   3. for each chunk index j (sequential: chunk j+1 needs the re-encoded motion of chunk j), all clips that
+//      still have a chunk j batched:  AdaLN table for all 12 blocks + head in ONE GEMM (the conditioning is
+//      layer-independent, app/transformer.py:32), K/V of the 181 history tokens once per layer, then the 5
+//      scale steps with a per-layer KV cache (only the new level's tokens run), VAE decode,
+//      re-encode + quantise to the next history.
+#include "kernels.h"
+#include "../../include/artalk_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace artalk;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr int kSamplesPerChunk = 64000;
+constexpr int kE = 768;      // embed dim (app/models.py:19)
+constexpr int kCond = 1024;  // audio feature dim (app/models.py:27)
+constexpr int kNTok = 181;
+constexpr int kMaxLv = 5;
+
+enum SlotKind { SK_DIRECT, SK_PADK, SK_CONV, SK_HOST, SK_IGNORE };
+
+struct Slot {
+    std::vector<int64_t> shape;
+    int dtype = ARTALK_DTYPE_F32;
+    SlotKind kind = SK_DIRECT;
+    float* dst = nullptr;      // device destination (DIRECT/PADK/CONV)
+    int64_t pad_to = 0;        // PADK: padded inner size
+    bool set = false;
+    std::vector<float> host;   // SK_HOST (and every small tensor) keeps a host copy
+    std::vector<int64_t> host_i64;
+    int64_t numel() const { int64_t n = 1; for (auto d : shape) n *= d; return n; }
+};
+
+struct W2VLayer { float *qkv_w, *qkv_b, *out_w, *out_b, *ln1w, *ln1b, *ln2w, *ln2b, *ff1_w, *ff1_b, *ff2_w, *ff2_b; };
+struct ARLayer { float *qkv_w, *qkv_b, *proj_w, *proj_b, *ffn1_w, *ffn1_b, *ffn2_w, *ffn2_b, *qscale; };
+struct VAELayer { float *lnw, *lnb, *qkv_w, *out_w, *out_b, *m1_w, *m1_b, *m2_w, *m2_b; };
+struct VAESide { float *in_w, *in_b, *out_w, *out_b; std::vector<VAELayer> layers; };
+struct StyleLayer { float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1w, *n1b, *n2w, *n2b; };
+
+struct Workspace {
+    int maxB = 0, maxC = 0, G = 0;   // G = wav2vec2 chunk-group size
+    // wav2vec2
+    long* src_off = nullptr; float *xnorm = nullptr, *convA = nullptr, *convB = nullptr;
+    float *h0 = nullptr, *h1 = nullptr, *xln = nullptr, *qkv = nullptr, *att = nullptr, *ffn = nullptr;
+    float* silu_cond = nullptr;     // [maxC*181, 1024]
+    // AR
+    float *ada = nullptr, *style_cond = nullptr, *prev_in = nullptr, *cache = nullptr;
+    float *x = nullptr, *xmod = nullptr, *attn_out = nullptr, *ffn_h = nullptr, *logits = nullptr;
+    float *fhat = nullptr, *nextfeat = nullptr;
+    uint8_t *bits = nullptr, *hist_bits = nullptr, *has_style = nullptr;
+    // VAE
+    float *prev_fdec = nullptr, *msfeat = nullptr, *dec_x = nullptr, *vh = nullptr, *vln = nullptr, *vqkv = nullptr;
+    float *vatt = nullptr, *vmlp = nullptr, *dec_out = nullptr, *enc_in = nullptr, *enc_out = nullptr, *motion_chunk = nullptr;
+    // style
+    float *s_in = nullptr, *s_h = nullptr, *s_qkv = nullptr, *s_att = nullptr, *s_ffn = nullptr, *s_tmp = nullptr;
+    int64_t bytes = 0;
+};
+
+}  // namespace
+
+struct artalk_model {
+    artalk_config cfg{};
+    int device = 0;
+    std::string err;
+    bool finalized = false;
+    std::map<std::string, Slot> slots;
+    std::vector<void*> allocs;
+    int64_t weight_bytes = 0;
+    // derived sizes
+    int n_conv = 0; int conv_T[8]{}; int conv_S[8]{};   // valid frames / padded row stride per conv layer output
+    int Tw = 0, Ts = 0;                                 // 199, 200
+    int ada_n = 0;                                      // 12*4608 + 1536
+    int pn[kMaxLv]{}, off[kMaxLv + 1]{};
+    // weights
+    float *conv0_w = nullptr, *conv_b[8]{}, *conv_lnw[8]{}, *conv_lnb[8]{}, *conv_w[8]{};
+    float *fp_lnw = nullptr, *fp_lnb = nullptr, *fp_w = nullptr, *fp_b = nullptr;
+    float *pos_w = nullptr, *pos_b = nullptr, *enc_lnw = nullptr, *enc_lnb = nullptr;
+    std::vector<W2VLayer> w2v;
+    float *ada_w = nullptr, *ada_b = nullptr;
+    std::vector<ARLayer> ar;
+    float *logits_w = nullptr, *logits_b = nullptr, *vq_w = nullptr, *vq_b = nullptr, *sc_w = nullptr, *sc_b = nullptr;
+    float *null_style = nullptr, *lvl_pos = nullptr, *prev_lvl_pos = nullptr;
+    float *enc_pos = nullptr, *dec_pos = nullptr, *vae_mean = nullptr, *vae_std = nullptr;
+    VAESide enc, dec;
+    float *st_mean = nullptr, *st_std = nullptr, *st_pe = nullptr, *st_proj_w = nullptr, *st_proj_b = nullptr;
+    std::vector<StyleLayer> style;
+    Workspace ws;
+    // profiling
+    bool profiling = false, use_graphs = true;
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    std::vector<std::pair<size_t, double>> dom_events;   // (event index of start, flops)
+    std::vector<std::pair<int, size_t>> marks;          // (bucket of the interval ending here, event index)
+    hipStream_t prof_stream = nullptr;
+    hipStream_t own_stream = nullptr;   // used when the caller passes stream == NULL (graph capture needs a real stream)
+    // graphs: one per active batch size
+    std::map<int, hipGraphExec_t> graphs;
+};
+
+namespace {
+
+#define HIPCHK(m, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (m)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            return ARTALK_EHIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+int fail(artalk_model* m, int code, const std::string& msg) { m->err = msg; return code; }
+
+template <typename T>
+T* dalloc(artalk_model* m, int64_t n, bool zero = true) {
+    void* p = nullptr;
+    if (n <= 0) n = 1;
+    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
+    if (zero) (void)hipMemset(p, 0, n * sizeof(T));
+    m->allocs.push_back(p);
+    return reinterpret_cast<T*>(p);
+}
+
+float* walloc(artalk_model* m, int64_t n) {
+    m->weight_bytes += n * 4;
+    return dalloc<float>(m, n);
+}
+
+void add_slot(artalk_model* m, const std::string& key, std::vector<int64_t> shape, SlotKind kind, float* dst,
+              int64_t pad_to = 0, int dtype = ARTALK_DTYPE_F32) {
+    Slot s;
+    s.shape = std::move(shape); s.kind = kind; s.dst = dst; s.pad_to = pad_to; s.dtype = dtype;
+    m->slots[key] = std::move(s);
+}
+
+// Linear: weight [out,in] (+bias) copied as is.
+void add_linear(artalk_model* m, const std::string& p, int out_f, int in_f, float*& w, float*& b, bool bias = true) {
+    w = walloc(m, (int64_t)out_f * in_f);
+    add_slot(m, p + ".weight", {out_f, in_f}, SK_DIRECT, w);
+    if (bias) { b = walloc(m, out_f); add_slot(m, p + ".bias", {out_f}, SK_DIRECT, b); } else b = nullptr;
+}
+void add_vec(artalk_model* m, const std::string& key, int n, float*& v) {
+    v = walloc(m, n);
+    add_slot(m, key, {n}, SK_DIRECT, v);
+}
+void add_ln(artalk_model* m, const std::string& p, int n, float*& w, float*& b) {
+    add_vec(m, p + ".weight", n, w);
+    add_vec(m, p + ".bias", n, b);
+}
+
+int build_registry(artalk_model* m) {
+    const artalk_config& c = m->cfg;
+    const int NT = kNTok;
+    // ---- top level (app/models.py:19-56) ----
+    add_slot(m, "null_style_cond", {1, 1, kE}, SK_DIRECT, m->null_style = walloc(m, kE));
+    add_slot(m, "pos_embed", {1, NT, kE}, SK_HOST, nullptr);
+    add_slot(m, "prev_pos_embed", {1, NT, kE}, SK_HOST, nullptr);
+    add_slot(m, "attn_bias_for_masking", {1, 1, NT, 2 * NT}, SK_HOST, nullptr);
+    add_slot(m, "lvl_idx", {1, NT}, SK_HOST, nullptr, 0, ARTALK_DTYPE_I64);
+    add_slot(m, "lvl_embed.weight", {c.n_levels, kE}, SK_HOST, nullptr);
+    m->lvl_pos = walloc(m, (int64_t)NT * kE);
+    m->prev_lvl_pos = walloc(m, (int64_t)NT * kE);
+    add_linear(m, "vqfeat_embed", kE, c.code_dim, m->vq_w, m->vq_b);
+    add_linear(m, "style_cond_embed", kE, c.style_dim, m->sc_w, m->sc_b);
+    add_linear(m, "logits_head", 2 * c.code_dim, kE, m->logits_w, m->logits_b);
+    // fused AdaLN table: rows [l*6E, (l+1)*6E) = block l, rows [depth*6E, depth*6E+2E) = head
+    m->ada_n = c.ar_depth * 6 * kE + 2 * kE;
+    m->ada_w = walloc(m, (int64_t)m->ada_n * kCond);
+    m->ada_b = walloc(m, m->ada_n);
+    add_slot(m, "cond_logits_head.ada_lin.1.weight", {2 * kE, kCond}, SK_DIRECT, m->ada_w + (int64_t)c.ar_depth * 6 * kE * kCond);
+    add_slot(m, "cond_logits_head.ada_lin.1.bias", {2 * kE}, SK_DIRECT, m->ada_b + c.ar_depth * 6 * kE);
+    m->ar.resize(c.ar_depth);
+    for (int i = 0; i < c.ar_depth; ++i) {
+        ARLayer& L = m->ar[i];
+        const std::string p = "attn_blocks." + std::to_string(i);
+        add_slot(m, p + ".attn.scale_mul_1H11", {1, c.ar_heads, 1, 1}, SK_HOST, nullptr);
+        L.qscale = walloc(m, c.ar_heads);
+        L.qkv_w = walloc(m, (int64_t)3 * kE * kE);
+        L.qkv_b = walloc(m, 3 * kE);     // key has no bias (app/transformer.py:61): stays zero
+        add_slot(m, p + ".attn.query.weight", {kE, kE}, SK_DIRECT, L.qkv_w);
+        add_slot(m, p + ".attn.query.bias", {kE}, SK_DIRECT, L.qkv_b);
+        add_slot(m, p + ".attn.key.weight", {kE, kE}, SK_DIRECT, L.qkv_w + (int64_t)kE * kE);
+        add_slot(m, p + ".attn.value.weight", {kE, kE}, SK_DIRECT, L.qkv_w + (int64_t)2 * kE * kE);
+        add_slot(m, p + ".attn.value.bias", {kE}, SK_DIRECT, L.qkv_b + 2 * kE);
+        add_linear(m, p + ".attn.proj", kE, kE, L.proj_w, L.proj_b);
+        add_linear(m, p + ".ffn.0", 4 * kE, kE, L.ffn1_w, L.ffn1_b);
+        add_linear(m, p + ".ffn.2", kE, 4 * kE, L.ffn2_w, L.ffn2_b);
+        add_slot(m, p + ".ada_lin.1.weight", {6 * kE, kCond}, SK_DIRECT, m->ada_w + (int64_t)i * 6 * kE * kCond);
+        add_slot(m, p + ".ada_lin.1.bias", {6 * kE}, SK_DIRECT, m->ada_b + i * 6 * kE);
+    }
+    // ---- VAE (app/modules/bitwise_vae.py) ----
+    const int H = c.vae_hidden, T2 = 2 * c.patch_nums[c.n_levels - 1], MD = c.motion_dim;
+    add_slot(m, "basic_vae.enc_pos_embed", {1, T2, MD}, SK_DIRECT, m->enc_pos = walloc(m, (int64_t)T2 * MD));
+    add_slot(m, "basic_vae.dec_pos_embed", {1, T2, c.code_dim}, SK_DIRECT, m->dec_pos = walloc(m, (int64_t)T2 * c.code_dim));
+    add_slot(m, "basic_vae.attn_mask", {1, 1, T2, T2}, SK_HOST, nullptr);
+    add_vec(m, "basic_vae.motion_mean", MD, m->vae_mean);
+    add_vec(m, "basic_vae.motion_std", MD, m->vae_std);
+    m->enc.in_w = walloc(m, (int64_t)H * 128);
+    add_slot(m, "basic_vae.encoder.inp_mapping.0.weight", {H, MD}, SK_PADK, m->enc.in_w, 128);
+    add_vec(m, "basic_vae.encoder.inp_mapping.0.bias", H, m->enc.in_b);
+    add_linear(m, "basic_vae.encoder.code_mapping", c.code_dim, H, m->enc.out_w, m->enc.out_b);
+    add_linear(m, "basic_vae.decoder.inp_mapping.0", H, c.code_dim, m->dec.in_w, m->dec.in_b);
+    add_linear(m, "basic_vae.decoder.out_mapping", MD, H, m->dec.out_w, m->dec.out_b);
+    for (int side = 0; side < 2; ++side) {
+        VAESide& S = side == 0 ? m->enc : m->dec;
+        const std::string base = side == 0 ? "basic_vae.encoder.encoder_transformer." : "basic_vae.decoder.decoder_transformer.";
+        S.layers.resize(c.vae_depth);
+        for (int i = 0; i < c.vae_depth; ++i) {
+            VAELayer& L = S.layers[i];
+            const std::string a = base + std::to_string(2 * i), f = base + std::to_string(2 * i + 1);
+            add_ln(m, a + ".norm", H, L.lnw, L.lnb);
+            float* nb = nullptr;
+            add_linear(m, a + ".to_qkv", 3 * H, H, L.qkv_w, nb, false);
+            add_linear(m, a + ".to_out", H, H, L.out_w, L.out_b);
+            add_linear(m, f + ".0", H * 3 / 2, H, L.m1_w, L.m1_b);
+            add_linear(m, f + ".2", H, H * 3 / 2, L.m2_w, L.m2_b);
+        }
+    }
+    // ---- style encoder (app/modules/style_encoder.py) ----
+    const int S = c.style_dim;
+    add_vec(m, "style_encoder.motion_mean", MD, m->st_mean);
+    add_vec(m, "style_encoder.motion_std", MD, m->st_std);
+    add_slot(m, "style_encoder.PE.pe", {1, 600, S}, SK_HOST, nullptr);
+    m->st_pe = walloc(m, S);
+    m->st_proj_w = walloc(m, (int64_t)S * 128);
+    add_slot(m, "style_encoder.encoder.motion_proj.weight", {S, MD}, SK_PADK, m->st_proj_w, 128);
+    add_vec(m, "style_encoder.encoder.motion_proj.bias", S, m->st_proj_b);
+    m->style.resize(c.style_layers);
+    for (int i = 0; i < c.style_layers; ++i) {
+        StyleLayer& L = m->style[i];
+        const std::string p = "style_encoder.encoder.transformer.layers." + std::to_string(i);
+        L.in_w = walloc(m, (int64_t)3 * S * S); L.in_b = walloc(m, 3 * S);
+        add_slot(m, p + ".self_attn.in_proj_weight", {3 * S, S}, SK_DIRECT, L.in_w);
+        add_slot(m, p + ".self_attn.in_proj_bias", {3 * S}, SK_DIRECT, L.in_b);
+        add_linear(m, p + ".self_attn.out_proj", S, S, L.out_w, L.out_b);
+        add_linear(m, p + ".linear1", c.style_ffn, S, L.l1_w, L.l1_b);
+        add_linear(m, p + ".linear2", S, c.style_ffn, L.l2_w, L.l2_b);
+        add_ln(m, p + ".norm1", S, L.n1w, L.n1b);
+        add_ln(m, p + ".norm2", S, L.n2w, L.n2b);
+    }
+    // ---- wav2vec2 ----
+    const int Hs = c.w2v_hidden, Fi = c.w2v_ffn, CD = c.w2v_conv_dim;
+    add_slot(m, "audio_encoder.masked_spec_embed", {Hs}, SK_IGNORE, nullptr);   // dead in inference
+    int cin = 1;
+    for (int i = 0; i < c.w2v_n_conv; ++i) {
+        const std::string p = "audio_encoder.feature_extractor.conv_layers." + std::to_string(i);
+        const int k = c.w2v_conv_kernel[i];
+        m->conv_w[i] = walloc(m, (int64_t)CD * cin * k);
+        add_slot(m, p + ".conv.weight", {CD, cin, k}, i == 0 ? SK_DIRECT : SK_CONV, m->conv_w[i]);
+        add_vec(m, p + ".conv.bias", CD, m->conv_b[i]);
+        add_ln(m, p + ".layer_norm", CD, m->conv_lnw[i], m->conv_lnb[i]);
+        cin = CD;
+    }
+    m->conv0_w = m->conv_w[0];
+    add_ln(m, "audio_encoder.feature_projection.layer_norm", CD, m->fp_lnw, m->fp_lnb);
+    add_linear(m, "audio_encoder.feature_projection.projection", Hs, CD, m->fp_w, m->fp_b);
+    const std::string pc = "audio_encoder.encoder.pos_conv_embed.conv";
+    add_vec(m, pc + ".bias", Hs, m->pos_b);
+    add_slot(m, pc + ".parametrizations.weight.original0", {1, 1, c.w2v_pos_kernel}, SK_HOST, nullptr);
+    add_slot(m, pc + ".parametrizations.weight.original1", {Hs, Hs / c.w2v_pos_groups, c.w2v_pos_kernel}, SK_HOST, nullptr);
+    m->pos_w = walloc(m, (int64_t)Hs * (Hs / c.w2v_pos_groups) * c.w2v_pos_kernel);
+    add_ln(m, "audio_encoder.encoder.layer_norm", Hs, m->enc_lnw, m->enc_lnb);
+    m->w2v.resize(c.w2v_layers);
+    for (int i = 0; i < c.w2v_layers; ++i) {
+        W2VLayer& L = m->w2v[i];
+        const std::string p = "audio_encoder.encoder.layers." + std::to_string(i);
+        L.qkv_w = walloc(m, (int64_t)3 * Hs * Hs); L.qkv_b = walloc(m, 3 * Hs);
+        const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int j = 0; j < 3; ++j) {
+            add_slot(m, p + ".attention." + names[j] + ".weight", {Hs, Hs}, SK_DIRECT, L.qkv_w + (int64_t)j * Hs * Hs);
+            add_slot(m, p + ".attention." + names[j] + ".bias", {Hs}, SK_DIRECT, L.qkv_b + j * Hs);
+        }
+        add_linear(m, p + ".attention.out_proj", Hs, Hs, L.out_w, L.out_b);
+        add_ln(m, p + ".layer_norm", Hs, L.ln1w, L.ln1b);
+        add_ln(m, p + ".final_layer_norm", Hs, L.ln2w, L.ln2b);
+        add_linear(m, p + ".feed_forward.intermediate_dense", Fi, Hs, L.ff1_w, L.ff1_b);
+        add_linear(m, p + ".feed_forward.output_dense", Hs, Fi, L.ff2_w, L.ff2_b);
+    }
+    for (void* p : m->allocs) if (!p) return fail(m, ARTALK_EHIP, "hipMalloc failed while allocating weights");
+    return ARTALK_OK;
+}
+
+int upload(artalk_model* m, float* dst, const float* src, int64_t n) {
+    HIPCHK(m, hipMemcpy(dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return ARTALK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+hipEvent_t next_event(artalk_model* m, hipStream_t s, size_t* idx) {
+    if (m->ev_used == m->ev_pool.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        m->ev_pool.push_back(e);
+    }
+    *idx = m->ev_used++;
+    (void)hipEventRecord(m->ev_pool[*idx], s);
+    return m->ev_pool[*idx];
+}
+// profile buckets (artalk_get_profile): the interval that ENDS at a mark is charged to the mark's bucket
+enum { PB_STYLE = 0, PB_CONV = 1, PB_ENC = 2, PB_ADA = 3, PB_AR = 4, PB_VAE = 5, PB_OTHER = 6 };
+void stage_mark(artalk_model* m, hipStream_t s, int bucket) {
+    if (!m->profiling) return;
+    size_t i;
+    next_event(m, s, &i);
+    m->marks.emplace_back(bucket, i);
+}
+
+void gemm(artalk_model* m, const GemmArgs& g, hipStream_t s) {
+    if (m->profiling && gemm_config(g) == 0 && g.M > 0) {
+        size_t i0, i1;
+        next_event(m, s, &i0);
+        launch_gemm(g, s);
+        next_event(m, s, &i1);
+        m->dom_events.emplace_back(i0, gemm_flops(g));
+    } else {
+        launch_gemm(g, s);
+    }
+}
+
+// plain y = act(x W^T + b) [+ R]
+void linear(artalk_model* m, const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N, int K,
+            int act, const float* R, hipStream_t s) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act;
+    g.R = R; g.ldr = ldc;
+    gemm(m, g, s);
+}
+
+void layernorm(const float* X, float* Y, const float* w, const float* b, int M, int D, float eps, int act, hipStream_t s) {
+    LnArgs a;
+    a.X = X; a.ldx = D; a.Y = Y; a.ldy = D; a.w = w; a.b = b; a.M = M; a.D = D; a.eps = eps; a.act = act;
+    launch_layernorm(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------ stages
+// wav2vec2 on chunks [c0, c0+n) of the chunk list (app/modules/wav2vec.py:11-20); writes SiLU(pooled cond) rows c0*181..
+void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_w2v, hipStream_t s) {
+    const artalk_config& c = m->cfg;
+    Workspace& w = m->ws;
+    const int CD = c.w2v_conv_dim, Hs = c.w2v_hidden;
+    launch_audio_normalize(audio, w.src_off + c0, w.xnorm, n, kSamplesPerChunk, s);
+    launch_conv0(w.xnorm, kSamplesPerChunk, m->conv0_w, m->conv_b[0], m->conv_lnw[0], m->conv_lnb[0], w.convA, n, m->conv_T[0],
+                 m->conv_S[0], s);
+    float* src = w.convA; float* dst = w.convB;
+    for (int i = 1; i < c.w2v_n_conv; ++i) {
+        // stride-2 conv as a GEMM: output row r reads input rows 2r..2r+k-1 (contiguous K = k*512 floats)
+        const int M = n * m->conv_S[i];
+        linear(m, src, (long)c.w2v_conv_stride[i] * CD, m->conv_w[i], m->conv_b[i], dst, CD, M, CD, c.w2v_conv_kernel[i] * CD,
+               ACT_NONE, nullptr, s);
+        layernorm(dst, dst, m->conv_lnw[i], m->conv_lnb[i], M, CD, 1e-5f, ACT_GELU_ERF, s);
+        std::swap(src, dst);
+    }
+    stage_mark(m, s, PB_CONV);
+    const int M = n * m->Ts;
+    // feature projection (hf:429-434)
+    layernorm(src, dst, m->fp_lnw, m->fp_lnb, M, CD, c.w2v_ln_eps, ACT_NONE, s);
+    linear(m, dst, CD, m->fp_w, m->fp_b, w.h0, Hs, M, Hs, CD, ACT_NONE, nullptr, s);
+    // positional conv embedding (hf:360-368): h1 = h0 + gelu(groupconv(h0) + b)
+    {
+        const int cg = Hs / c.w2v_pos_groups;
+        GemmArgs g;
+        g.A = w.h0; g.lda = Hs; g.amode = 1; g.pc_T = m->Tw; g.pc_tstride = m->Ts; g.pc_pad = c.w2v_pos_kernel / 2; g.pc_cin = cg;
+        g.W = m->pos_w; g.ldw = (long)cg * c.w2v_pos_kernel; g.bias = m->pos_b; g.C = w.h1; g.ldc = Hs; g.R = w.h0; g.ldr = Hs;
+        g.M = M; g.N = cg; g.K = cg * c.w2v_pos_kernel; g.act = ACT_GELU_ERF;
+        g.batch = c.w2v_pos_groups; g.sA = cg; g.sW = (long)cg * cg * c.w2v_pos_kernel; g.sBias = cg; g.sC = cg; g.sR = cg;
+        gemm(m, g, s);
+    }
+    float* h = w.h1;
+    const int nh = c.w2v_heads, hd = Hs / nh;
+    for (int i = 0; i < c.w2v_layers; ++i) {
+        const W2VLayer& L = m->w2v[i];
+        layernorm(h, w.xln, L.ln1w, L.ln1b, M, Hs, c.w2v_ln_eps, ACT_NONE, s);
+        linear(m, w.xln, Hs, L.qkv_w, L.qkv_b, w.qkv, 3 * Hs, M, 3 * Hs, Hs, ACT_NONE, nullptr, s);
+        AttnArgs a;
+        a.Q = w.qkv; a.K = w.qkv + Hs; a.V = w.qkv + 2 * Hs;
+        a.ldq = a.ldk = a.ldv = 3 * Hs; a.q_bstride = a.k_bstride = a.v_bstride = (long)m->Ts * 3 * Hs;
+        a.O = w.att; a.ldo = Hs; a.o_bstride = (long)m->Ts * Hs;
+        a.B = n; a.H = nh; a.HD = hd; a.Lq = m->Tw; a.Lk = m->Tw; a.scale = 1.0f / std::sqrt((float)hd);
+        launch_attention(a, s);
+        linear(m, w.att, Hs, L.out_w, L.out_b, h, Hs, M, Hs, Hs, ACT_NONE, h, s);
+        layernorm(h, w.xln, L.ln2w, L.ln2b, M, Hs, c.w2v_ln_eps, ACT_NONE, s);
+        linear(m, w.xln, Hs, L.ff1_w, L.ff1_b, w.ffn, c.w2v_ffn, M, c.w2v_ffn, Hs, ACT_GELU_ERF, nullptr, s);
+        linear(m, w.ffn, c.w2v_ffn, L.ff2_w, L.ff2_b, h, Hs, M, Hs, c.w2v_ffn, ACT_NONE, h, s);
+    }
+    layernorm(h, w.xln, m->enc_lnw, m->enc_lnb, M, Hs, c.w2v_ln_eps, ACT_NONE, s);
+    if (out_w2v)
+        (void)hipMemcpy2DAsync(out_w2v + (long)c0 * m->Tw * Hs, (size_t)m->Tw * Hs * 4, w.xln, (size_t)m->Ts * Hs * 4,
+                               (size_t)m->Tw * Hs * 4, n, hipMemcpyDeviceToDevice, s);
+    launch_pool_silu(w.xln, m->Ts, m->Tw, w.silu_cond + (long)c0 * kNTok * kCond, n, m->pn, c.n_levels, kCond, s);
+    stage_mark(m, s, PB_ENC);
+}
+
+void run_style(artalk_model* m, const float* style_motion, int B, hipStream_t s) {
+    const artalk_config& c = m->cfg;
+    Workspace& w = m->ws;
+    const int S = c.style_dim, L = c.style_len, M = B * L;
+    if (style_motion) {
+        launch_style_input(style_motion, m->st_mean, m->st_std, w.s_in, B, s);
+        linear(m, w.s_in, 128, m->st_proj_w, m->st_proj_b, w.s_h, S, M, S, 128, ACT_NONE, nullptr, s);
+        launch_add_row(w.s_h, m->st_pe, M, S, s);   // PositionalEncoding quirk: pe[:, seq_len] added to every token
+        for (int i = 0; i < c.style_layers; ++i) {
+            const StyleLayer& Ly = m->style[i];
+            linear(m, w.s_h, S, Ly.in_w, Ly.in_b, w.s_qkv, 3 * S, M, 3 * S, S, ACT_NONE, nullptr, s);
+            AttnArgs a;
+            a.Q = w.s_qkv; a.K = w.s_qkv + S; a.V = w.s_qkv + 2 * S; a.ldq = a.ldk = a.ldv = 3 * S;
+            a.q_bstride = a.k_bstride = a.v_bstride = (long)L * 3 * S;
+            a.O = w.s_att; a.ldo = S; a.o_bstride = (long)L * S;
+            a.B = B; a.H = c.style_heads; a.HD = S / c.style_heads; a.Lq = L; a.Lk = L;
+            a.scale = 1.0f / std::sqrt((float)(S / c.style_heads));
+            launch_attention(a, s);
+            linear(m, w.s_att, S, Ly.out_w, Ly.out_b, w.s_tmp, S, M, S, S, ACT_NONE, w.s_h, s);
+            layernorm(w.s_tmp, w.s_h, Ly.n1w, Ly.n1b, M, S, 1e-5f, ACT_NONE, s);
+            linear(m, w.s_h, S, Ly.l1_w, Ly.l1_b, w.s_ffn, c.style_ffn, M, c.style_ffn, S, ACT_GELU_ERF, nullptr, s);
+            linear(m, w.s_ffn, c.style_ffn, Ly.l2_w, Ly.l2_b, w.s_tmp, S, M, S, c.style_ffn, ACT_NONE, w.s_h, s);
+            layernorm(w.s_tmp, w.s_h, Ly.n2w, Ly.n2b, M, S, 1e-5f, ACT_NONE, s);
+        }
+    }
+    launch_style_finish(w.s_h, m->sc_w, m->sc_b, m->null_style, style_motion ? w.has_style : nullptr, w.style_cond, B, s);
+}
+
+// one VAE transformer stack (app/modules/bitwise_vae.py:149-157 / :183-191) on B sequences of T tokens, in place on ws.vh
+void run_vae_stack(artalk_model* m, const VAESide& S, int B, int T, int split, hipStream_t s) {
+    const artalk_config& c = m->cfg;
+    Workspace& w = m->ws;
+    const int H = c.vae_hidden, M = B * T, F = H * 3 / 2;
+    for (int i = 0; i < c.vae_depth; ++i) {
+        const VAELayer& L = S.layers[i];
+        layernorm(w.vh, w.vln, L.lnw, L.lnb, M, H, 1e-5f, ACT_NONE, s);
+        linear(m, w.vln, H, L.qkv_w, nullptr, w.vqkv, 3 * H, M, 3 * H, H, ACT_NONE, nullptr, s);
+        AttnArgs a;
+        a.Q = w.vqkv; a.K = w.vqkv + H; a.V = w.vqkv + 2 * H; a.ldq = a.ldk = a.ldv = 3 * H;
+        a.q_bstride = a.k_bstride = a.v_bstride = (long)T * 3 * H;
+        a.O = w.vatt; a.ldo = H; a.o_bstride = (long)T * H;
+        a.B = B; a.H = c.vae_heads; a.HD = H / c.vae_heads; a.Lq = T; a.Lk = T;
+        a.scale = 1.0f / std::sqrt((float)H);      // hidden_dim**-0.5, NOT head_dim (bitwise_vae.py:198)
+        a.split_q = split; a.split_k = split;
+        launch_attention(a, s);
+        linear(m, w.vatt, H, L.out_w, L.out_b, w.vh, H, M, H, H, ACT_NONE, w.vh, s);
+        linear(m, w.vh, H, L.m1_w, L.m1_b, w.vmlp, F, M, F, H, ACT_GELU_TANH, nullptr, s);
+        linear(m, w.vmlp, F, L.m2_w, L.m2_b, w.vh, H, M, H, F, ACT_NONE, w.vh, s);
+    }
+}
+
+// motion (already in ws.enc_in as normalised + pos-embedded rows) -> history bits, decoder features, prev tokens
+void run_reencode(artalk_model* m, int B, hipStream_t s) {
+    const artalk_config& c = m->cfg;
+    Workspace& w = m->ws;
+    const int H = c.vae_hidden, T = 100;
+    linear(m, w.enc_in, 128, m->enc.in_w, m->enc.in_b, w.vh, H, B * T, H, 128, ACT_LEAKY02, nullptr, s);
+    run_vae_stack(m, m->enc, B, T, 0, s);
+    linear(m, w.vh, H, m->enc.out_w, m->enc.out_b, w.enc_out, c.code_dim, B * T, c.code_dim, H, ACT_NONE, nullptr, s);
+    launch_bsq_history(w.enc_out, w.hist_bits, w.prev_fdec, w.msfeat, B, s);
+    launch_vq_embed(w.msfeat, kNTok - 1, m->vq_w, m->vq_b, m->prev_lvl_pos + kE, w.prev_in, kNTok, 1, w.style_cond,
+                    m->prev_lvl_pos, B, s);
+}
+
+// Everything of one chunk index that depends only on (B, fixed workspace pointers): capturable as one hipGraph.
+void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
+    const artalk_config& c = m->cfg;
+    Workspace& w = m->ws;
+    const long ldada = m->ada_n;
+    const long cache_l = (long)w.maxB * 2 * kNTok * 3 * kE;   // floats per layer
+    // K/V of the 181 history tokens, once per layer (raw prev tokens, not modulated: app/transformer.py:68-70)
+    for (int l = 0; l < c.ar_depth; ++l) {
+        const ARLayer& L = m->ar[l];
+        GemmArgs g;
+        g.A = w.prev_in; g.lda = kE; g.W = L.qkv_w + (long)kE * kE; g.ldw = kE; g.bias = L.qkv_b + kE;
+        g.C = w.cache + l * cache_l + kE; g.ldc = 3 * kE; g.cmap = rowmap(kNTok, 2 * kNTok, 0);
+        g.M = B * kNTok; g.N = 2 * kE; g.K = kE;
+        gemm(m, g, s);
+    }
+    launch_ar_begin(w.style_cond, m->lvl_pos, w.x, w.fhat, B, s);
+    for (int p = 0; p < c.n_levels; ++p) {
+        const int pn = m->pn[p], off = m->off[p], M = B * pn;
+        const RowMap amap = rowmap(pn, kNTok, off);            // rows of the AdaLN table for this level's tokens
+        for (int l = 0; l < c.ar_depth; ++l) {
+            const ARLayer& L = m->ar[l];
+            const float* ada = w.ada + (long)l * 6 * kE;       // gamma1,gamma2,scale1,scale2,shift1,shift2 (app/transformer.py:32)
+            float* cache = w.cache + l * cache_l;
+            LnArgs n1;
+            n1.X = w.x; n1.ldx = kE; n1.Y = w.xmod; n1.ldy = kE; n1.scale = ada + 2 * kE; n1.shift = ada + 4 * kE; n1.ldm = ldada;
+            n1.mmap = amap; n1.M = M; n1.D = kE; n1.eps = 1e-6f;
+            launch_layernorm(n1, s);
+            GemmArgs q;
+            q.A = w.xmod; q.lda = kE; q.W = L.qkv_w; q.ldw = kE; q.bias = L.qkv_b; q.C = cache; q.ldc = 3 * kE;
+            q.cmap = rowmap(pn, 2 * kNTok, kNTok + off); q.M = M; q.N = 3 * kE; q.K = kE;
+            gemm(m, q, s);
+            AttnArgs a;
+            a.Q = cache + (long)(kNTok + off) * 3 * kE; a.K = cache + kE; a.V = cache + 2 * kE;
+            a.ldq = a.ldk = a.ldv = 3 * kE; a.q_bstride = a.k_bstride = a.v_bstride = (long)2 * kNTok * 3 * kE;
+            a.O = w.attn_out; a.ldo = kE; a.o_bstride = (long)pn * kE;
+            a.B = B; a.H = c.ar_heads; a.HD = kE / c.ar_heads; a.Lq = pn; a.Lk = kNTok + off + pn; a.scale = 1.0f;
+            a.l2norm = 1; a.qscale = L.qscale;
+            launch_attention(a, s);
+            GemmArgs pj;
+            pj.A = w.attn_out; pj.lda = kE; pj.W = L.proj_w; pj.ldw = kE; pj.bias = L.proj_b; pj.C = w.x; pj.ldc = kE;
+            pj.gate = ada; pj.ldg = ldada; pj.gmap = amap; pj.R = w.x; pj.ldr = kE; pj.M = M; pj.N = kE; pj.K = kE;
+            gemm(m, pj, s);
+            LnArgs n2 = n1;
+            n2.scale = ada + 3 * kE; n2.shift = ada + 5 * kE;
+            launch_layernorm(n2, s);
+            linear(m, w.xmod, kE, L.ffn1_w, L.ffn1_b, w.ffn_h, 4 * kE, M, 4 * kE, kE, ACT_GELU_TANH, nullptr, s);
+            GemmArgs f2;
+            f2.A = w.ffn_h; f2.lda = 4 * kE; f2.W = L.ffn2_w; f2.ldw = 4 * kE; f2.bias = L.ffn2_b; f2.C = w.x; f2.ldc = kE;
+            f2.gate = ada + kE; f2.ldg = ldada; f2.gmap = amap; f2.R = w.x; f2.ldr = kE; f2.M = M; f2.N = kE; f2.K = 4 * kE;
+            gemm(m, f2, s);
+        }
+        // head (app/models.py:145-148,103): scale, shift = split2
+        const float* hada = w.ada + (long)c.ar_depth * 6 * kE;
+        LnArgs nh;
+        nh.X = w.x; nh.ldx = kE; nh.Y = w.xmod; nh.ldy = kE; nh.scale = hada; nh.shift = hada + kE; nh.ldm = ldada; nh.mmap = amap;
+        nh.M = M; nh.D = kE; nh.eps = 1e-6f;
+        launch_layernorm(nh, s);
+        linear(m, w.xmod, kE, m->logits_w, m->logits_b, w.logits, 2 * c.code_dim, M, 2 * c.code_dim, kE, ACT_NONE, nullptr, s);
+        launch_ar_bits_next(w.logits, w.bits, w.fhat, w.nextfeat, B, p, s);
+        if (p + 1 < c.n_levels)
+            launch_vq_embed(w.nextfeat, m->pn[p + 1], m->vq_w, m->vq_b, m->lvl_pos + (long)m->off[p + 1] * kE, w.x, m->pn[p + 1], 0,
+                            nullptr, nullptr, B, s);
+    }
+    stage_mark(m, s, PB_AR);
+    // ---- VAE decode of [history | current] (bitwise_vae.py:105-113) ----
+    const int H = c.vae_hidden;
+    launch_dec_input(w.prev_fdec, w.fhat, w.bits, m->dec_pos, w.dec_x, B, s);
+    linear(m, w.dec_x, c.code_dim, m->dec.in_w, m->dec.in_b, w.vh, H, B * 200, H, c.code_dim, ACT_LEAKY02, nullptr, s);
+    run_vae_stack(m, m->dec, B, 200, 100, s);
+    linear(m, w.vh, H, m->dec.out_w, m->dec.out_b, w.dec_out, c.motion_dim, B * 200, c.motion_dim, H, ACT_NONE, nullptr, s);
+    launch_dec_finish(w.dec_out, m->vae_mean, m->vae_std, m->enc_pos, w.motion_chunk, 100L * c.motion_dim, 0, w.enc_in, B, s);
+    // ---- re-encode the generated motion into the next history (app/models.py:111-114) ----
+    run_reencode(m, B, s);
+    stage_mark(m, s, PB_VAE);
+}
+
+int reserve(artalk_model* m, int maxB, int maxC) {
+    const artalk_config& c = m->cfg;
+    Workspace& w = m->ws;
+    if (maxB <= w.maxB && maxC <= w.maxC) return ARTALK_OK;
+    if (w.maxB > 0) return fail(m, ARTALK_ECAPACITY, "workspace already reserved with a smaller capacity (destroy and re-create)");
+    const int CD = c.w2v_conv_dim, Hs = c.w2v_hidden;
+    w.maxB = maxB; w.maxC = maxC; w.G = std::min(maxC, 96);
+    const int64_t before = (int64_t)m->allocs.size();
+    auto F = [&](int64_t n) { w.bytes += n * 4; return dalloc<float>(m, n); };
+    const int G = w.G;
+    w.src_off = dalloc<long>(m, maxC);
+    w.xnorm = F((int64_t)G * kSamplesPerChunk);
+    w.convA = F(((int64_t)G * m->conv_S[0] + 16) * CD);
+    w.convB = F(((int64_t)G * m->conv_S[1] + 16) * CD);
+    const int64_t M = (int64_t)G * m->Ts;
+    w.h0 = F(M * Hs); w.h1 = F(M * Hs); w.xln = F(M * Hs); w.qkv = F(M * 3 * Hs); w.att = F(M * Hs); w.ffn = F(M * c.w2v_ffn);
+    w.silu_cond = F((int64_t)maxC * kNTok * kCond);
+    w.ada = F((int64_t)maxB * kNTok * m->ada_n);
+    w.style_cond = F((int64_t)maxB * kE);
+    w.prev_in = F((int64_t)maxB * kNTok * kE);
+    w.cache = F((int64_t)c.ar_depth * maxB * 2 * kNTok * 3 * kE);
+    w.x = F((int64_t)maxB * 100 * kE); w.xmod = F((int64_t)maxB * 100 * kE); w.attn_out = F((int64_t)maxB * 100 * kE);
+    w.ffn_h = F((int64_t)maxB * 100 * 4 * kE); w.logits = F((int64_t)maxB * 100 * 2 * c.code_dim);
+    w.fhat = F((int64_t)maxB * 100 * c.code_dim); w.nextfeat = F((int64_t)maxB * 100 * c.code_dim);
+    w.bits = dalloc<uint8_t>(m, (int64_t)maxB * kNTok * c.code_dim);
+    w.hist_bits = dalloc<uint8_t>(m, (int64_t)maxB * kNTok * c.code_dim);
+    w.has_style = dalloc<uint8_t>(m, maxB);
+    w.prev_fdec = F((int64_t)maxB * 100 * c.code_dim); w.msfeat = F((int64_t)maxB * 180 * c.code_dim);
+    const int H = c.vae_hidden;
+    w.dec_x = F((int64_t)maxB * 200 * c.code_dim); w.vh = F((int64_t)maxB * 200 * H); w.vln = F((int64_t)maxB * 200 * H);
+    w.vqkv = F((int64_t)maxB * 200 * 3 * H); w.vatt = F((int64_t)maxB * 200 * H); w.vmlp = F((int64_t)maxB * 200 * H * 3 / 2);
+    w.dec_out = F((int64_t)maxB * 200 * c.motion_dim); w.enc_in = F((int64_t)maxB * 100 * 128);
+    w.enc_out = F((int64_t)maxB * 100 * c.code_dim); w.motion_chunk = F((int64_t)maxB * 100 * c.motion_dim);
+    const int S = c.style_dim, SL = c.style_len;
+    w.s_in = F((int64_t)maxB * SL * 128); w.s_h = F((int64_t)maxB * SL * S); w.s_qkv = F((int64_t)maxB * SL * 3 * S);
+    w.s_att = F((int64_t)maxB * SL * S); w.s_ffn = F((int64_t)maxB * SL * c.style_ffn); w.s_tmp = F((int64_t)maxB * SL * S);
+    for (size_t i = before; i < m->allocs.size(); ++i)
+        if (!m->allocs[i]) return fail(m, ARTALK_EHIP, "hipMalloc failed while reserving workspace");
+    return ARTALK_OK;
+}
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" {
+
+const char* artalk_last_error(const artalk_model* m) { return m ? m->err.c_str() : g_create_error.c_str(); }
+
+int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return ARTALK_EINVAL; }
+    const artalk_config& c = *cfg;
+    static const int want_pn[5] = {1, 5, 25, 50, 100};
+    bool ok = c.n_levels == 5 && c.code_dim == 32 && c.motion_dim == 106 && c.vae_hidden == 512 && c.w2v_hidden == kCond &&
+              c.w2v_conv_dim == 512 && c.w2v_n_conv >= 2 && c.w2v_n_conv <= 8 && c.ar_heads * 64 == kE && c.vae_heads * 64 == c.vae_hidden &&
+              c.w2v_heads * 64 == c.w2v_hidden && c.style_dim == 128 && c.style_heads * 32 == c.style_dim && c.style_len == 50 &&
+              c.w2v_conv_kernel[0] == 10 && c.w2v_conv_stride[0] == 5 && c.w2v_ffn % 32 == 0 && c.style_ffn % 32 == 0;
+    for (int i = 0; ok && i < 5; ++i) ok = c.patch_nums[i] == want_pn[i];
+    if (!ok) { g_create_error = "unsupported configuration (kernels are specialised for assets/config.json + XLS-R-300M widths)"; return ARTALK_EINVAL; }
+    if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return ARTALK_EHIP; }
+    artalk_model* m = new artalk_model();
+    m->cfg = c; m->device = device_id;
+    // conv stack geometry: T_l valid frames; row stride S_l per chunk with S_l = 2*S_{l+1} so that one GEMM covers all chunks
+    int T = kSamplesPerChunk;
+    for (int i = 0; i < c.w2v_n_conv; ++i) { T = (T - c.w2v_conv_kernel[i]) / c.w2v_conv_stride[i] + 1; m->conv_T[i] = T; }
+    m->n_conv = c.w2v_n_conv; m->Tw = T; m->Ts = T + 1;
+    int S = m->Ts;
+    for (int i = c.w2v_n_conv - 1; i >= 0; --i) {
+        m->conv_S[i] = S;
+        if (i > 0) {
+            if (c.w2v_conv_stride[i] != 2 || m->conv_T[i - 1] > 2 * S) { g_create_error = "conv stack geometry unsupported"; delete m; return ARTALK_EINVAL; }
+            S *= 2;
+        }
+    }
+    for (int i = 0; i < 5; ++i) { m->pn[i] = c.patch_nums[i]; m->off[i + 1] = m->off[i] + c.patch_nums[i]; }
+    init_ms_tables();
+    if (hipStreamCreate(&m->own_stream) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete m; return ARTALK_EHIP; }
+    const int rc = build_registry(m);
+    if (rc != ARTALK_OK) { g_create_error = m->err; artalk_destroy(m); return rc; }
+    *out = m;
+    return ARTALK_OK;
+}
+
+void artalk_destroy(artalk_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
+    for (auto e : m->ev_pool) (void)hipEventDestroy(e);
+    if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+    for (void* p : m->allocs) if (p) (void)hipFree(p);
+    delete m;
+}
+
+int artalk_set_tensor(artalk_model* m, const char* key, const void* host_ptr, int dtype, int ndim, const int64_t* shape) {
+    if (!m || !key || !host_ptr || !shape) return ARTALK_EINVAL;
+    auto it = m->slots.find(key);
+    if (it == m->slots.end()) return fail(m, ARTALK_EKEY, std::string("Unexpected key in state_dict: ") + key);
+    Slot& s = it->second;
+    bool same = (int)s.shape.size() == ndim && dtype == s.dtype;
+    for (int i = 0; same && i < ndim; ++i) same = s.shape[i] == shape[i];
+    if (!same) return fail(m, ARTALK_EINVAL, std::string("size mismatch for ") + key);
+    (void)hipSetDevice(m->device);
+    const int64_t n = s.numel();
+    if (dtype == ARTALK_DTYPE_I64) {
+        s.host_i64.assign((const int64_t*)host_ptr, (const int64_t*)host_ptr + n);
+        s.set = true;
+        return ARTALK_OK;
+    }
+    const float* src = (const float*)host_ptr;
+    if (s.kind == SK_HOST || n <= 4096) s.host.assign(src, src + n);
+    int rc = ARTALK_OK;
+    switch (s.kind) {
+        case SK_DIRECT: rc = upload(m, s.dst, src, n); break;
+        case SK_PADK: {   // [out, in] -> [out, pad_to], zero padded
+            const int64_t o = s.shape[0], in = s.shape[1];
+            std::vector<float> t((size_t)o * s.pad_to, 0.f);
+            for (int64_t r = 0; r < o; ++r) std::memcpy(&t[r * s.pad_to], src + r * in, in * sizeof(float));
+            rc = upload(m, s.dst, t.data(), (int64_t)t.size());
+            break;
+        }
+        case SK_CONV: {   // [out, cin, k] -> [out, k, cin]: the K index of the conv-as-GEMM is tap*cin + ci
+            const int64_t o = s.shape[0], ci = s.shape[1], k = s.shape[2];
+            std::vector<float> t((size_t)n);
+            for (int64_t a = 0; a < o; ++a)
+                for (int64_t b = 0; b < ci; ++b)
+                    for (int64_t d = 0; d < k; ++d) t[(a * k + d) * ci + b] = src[(a * ci + b) * k + d];
+            rc = upload(m, s.dst, t.data(), n);
+            break;
+        }
+        default: break;
+    }
+    if (rc == ARTALK_OK) s.set = true;
+    return rc;
+}
+
+int artalk_finalize_weights(artalk_model* m) {
+    if (!m) return ARTALK_EINVAL;
+    (void)hipSetDevice(m->device);
+    std::string missing;
+    int nmiss = 0;
+    for (auto& kv : m->slots)
+        if (!kv.second.set) { if (nmiss++ < 8) missing += (missing.empty() ? "" : ", ") + kv.first; }
+    if (nmiss) return fail(m, ARTALK_EMISSING, "Missing key(s) in state_dict: " + missing + (nmiss > 8 ? ", ..." : ""));
+    const artalk_config& c = m->cfg;
+    // level / position tables (app/models.py:74-75)
+    {
+        const Slot& li = m->slots["lvl_idx"]; const Slot& le = m->slots["lvl_embed.weight"];
+        const Slot& pe = m->slots["pos_embed"]; const Slot& ppe = m->slots["prev_pos_embed"];
+        std::vector<float> a((size_t)kNTok * kE), b((size_t)kNTok * kE);
+        int tok = 0;
+        for (int p = 0; p < c.n_levels; ++p)
+            for (int i = 0; i < c.patch_nums[p]; ++i, ++tok)
+                if (li.host_i64[tok] != p) return fail(m, ARTALK_EINVAL, "lvl_idx does not match V_PATCH_NUMS");
+        for (int t = 0; t < kNTok; ++t)
+            for (int e = 0; e < kE; ++e) {
+                const float lv = le.host[(size_t)li.host_i64[t] * kE + e];
+                a[(size_t)t * kE + e] = lv + pe.host[(size_t)t * kE + e];
+                b[(size_t)t * kE + e] = lv + ppe.host[(size_t)t * kE + e];
+            }
+        if (int rc = upload(m, m->lvl_pos, a.data(), (int64_t)a.size())) return rc;
+        if (int rc = upload(m, m->prev_lvl_pos, b.data(), (int64_t)b.size())) return rc;
+        // the masks are implied by patch_nums (block-causal by level; VAE: history rows see history only); verify
+        const Slot& mk = m->slots["attn_bias_for_masking"];
+        for (int q = 0; q < kNTok; ++q)
+            for (int k = 0; k < 2 * kNTok; ++k) {
+                const float v = mk.host[(size_t)q * 2 * kNTok + k];
+                const bool vis = k < kNTok || li.host_i64[q] >= li.host_i64[k - kNTok];
+                if (vis ? (v != 0.f) : !(std::isinf(v) && v < 0)) return fail(m, ARTALK_EINVAL, "attn_bias_for_masking is not the level-causal mask");
+            }
+        const Slot& vm = m->slots["basic_vae.attn_mask"];
+        for (int q = 0; q < 200; ++q)
+            for (int k = 0; k < 200; ++k) {
+                const float v = vm.host[(size_t)q * 200 + k];
+                const bool vis = !(q < 100 && k >= 100);
+                if (vis ? (v != 0.f) : !(std::isinf(v) && v < 0)) return fail(m, ARTALK_EINVAL, "basic_vae.attn_mask is not the expected mask");
+            }
+    }
+    // learned attention scale: exp(min(scale_mul, log 100))  (app/transformer.py:72)
+    for (int i = 0; i < c.ar_depth; ++i) {
+        const Slot& sm = m->slots["attn_blocks." + std::to_string(i) + ".attn.scale_mul_1H11"];
+        std::vector<float> q(c.ar_heads);
+        for (int h = 0; h < c.ar_heads; ++h) q[h] = std::exp(std::min(sm.host[h], (float)std::log(100.0)));
+        if (int rc = upload(m, m->ar[i].qscale, q.data(), c.ar_heads)) return rc;
+    }
+    // style PE row pe[:, seq_len]  (style_encoder.py:59)
+    {
+        const Slot& pe = m->slots["style_encoder.PE.pe"];
+        if (int rc = upload(m, m->st_pe, pe.host.data() + (size_t)c.style_len * c.style_dim, c.style_dim)) return rc;
+    }
+    // pos-conv weight-norm fold (dim=2): w[o,i,k] = g[k] * v[o,i,k] / ||v[:,:,k]||, re-laid out [o][k][i]
+    {
+        const std::string pc = "audio_encoder.encoder.pos_conv_embed.conv.parametrizations.weight.";
+        const Slot& g = m->slots[pc + "original0"]; const Slot& v = m->slots[pc + "original1"];
+        const int64_t O = v.shape[0], I = v.shape[1], K = v.shape[2];
+        std::vector<double> nrm(K, 0.0);
+        for (int64_t o = 0; o < O; ++o)
+            for (int64_t i = 0; i < I; ++i)
+                for (int64_t k = 0; k < K; ++k) { const double x = v.host[(o * I + i) * K + k]; nrm[k] += x * x; }
+        std::vector<float> t((size_t)O * I * K);
+        for (int64_t k = 0; k < K; ++k) {
+            const float nk = (float)std::sqrt(nrm[k]);
+            for (int64_t o = 0; o < O; ++o)
+                for (int64_t i = 0; i < I; ++i) t[(o * K + k) * I + i] = v.host[(o * I + i) * K + k] * (g.host[k] / nk);
+        }
+        if (int rc = upload(m, m->pos_w, t.data(), (int64_t)t.size())) return rc;
+    }
+    for (auto& kv : m->slots) { std::vector<float>().swap(kv.second.host); }
+    m->finalized = true;
+    return ARTALK_OK;
+}
+
+int artalk_reserve(artalk_model* m, int max_batch, int max_total_chunks) {
+    if (!m || max_batch <= 0 || max_total_chunks < max_batch) return ARTALK_EINVAL;
+    (void)hipSetDevice(m->device);
+    return reserve(m, max_batch, max_total_chunks);
+}
+int64_t artalk_workspace_bytes(const artalk_model* m) { return m ? m->ws.bytes : 0; }
+int64_t artalk_weight_bytes(const artalk_model* m) { return m ? m->weight_bytes : 0; }
+
+int artalk_set_profiling(artalk_model* m, int enable) { if (!m) return ARTALK_EINVAL; m->profiling = enable != 0; return ARTALK_OK; }
+int artalk_set_graphs(artalk_model* m, int enable) { if (!m) return ARTALK_EINVAL; m->use_graphs = enable != 0; return ARTALK_OK; }
+
+int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_stride, const int64_t* n_chunks, int B,
+                 const float* style_motion_dev, const uint8_t* has_style, float* out_motion_dev, int64_t out_clip_stride,
+                 uint8_t* out_bits_dev, uint8_t* out_hist_bits_dev, float* out_w2v_dev, void* stream) {
+    if (!m || !audio_dev || !n_chunks || !out_motion_dev || B <= 0) return ARTALK_EINVAL;
+    if (!m->finalized) return fail(m, ARTALK_ESTATE, "artalk_infer before artalk_finalize_weights");
+    (void)hipSetDevice(m->device);
+    hipStream_t s = stream ? (hipStream_t)stream : m->own_stream;
+    const artalk_config& c = m->cfg;
+    int64_t C = 0, maxch = n_chunks[0];
+    for (int b = 0; b < B; ++b) {
+        if (n_chunks[b] <= 0 || (b > 0 && n_chunks[b] > n_chunks[b - 1])) return fail(m, ARTALK_EINVAL, "n_chunks must be positive and non-increasing");
+        C += n_chunks[b];
+    }
+    if (B > m->ws.maxB || C > m->ws.maxC) {
+        if (m->ws.maxB == 0) { if (int rc = reserve(m, B, (int)C)) return rc; }
+        else return fail(m, ARTALK_ECAPACITY, "batch exceeds the reserved workspace");
+    }
+    Workspace& w = m->ws;
+    // chunk list, chunk-index major: chunk (j, b) for all b with n_chunks[b] > j  -> active clips are a prefix
+    std::vector<long> src((size_t)C);
+    std::vector<int> base((size_t)maxch + 1, 0), Bj((size_t)maxch, 0);
+    {
+        int idx = 0;
+        for (int64_t j = 0; j < maxch; ++j) {
+            base[j] = idx;
+            for (int b = 0; b < B && n_chunks[b] > j; ++b) { src[idx++] = (long)b * audio_clip_stride + (long)j * kSamplesPerChunk; Bj[j]++; }
+        }
+        base[maxch] = idx;
+    }
+    HIPCHK(m, hipMemcpyAsync(w.src_off, src.data(), C * sizeof(long), hipMemcpyHostToDevice, s));
+    if (style_motion_dev && has_style) HIPCHK(m, hipMemcpyAsync(w.has_style, has_style, B, hipMemcpyHostToDevice, s));
+    HIPCHK(m, hipStreamSynchronize(s));   // src/has_style are stack/heap temporaries of this call
+    m->ev_used = 0; m->dom_events.clear(); m->marks.clear(); m->prof_stream = s;
+    stage_mark(m, s, PB_OTHER);
+    run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s);
+    stage_mark(m, s, PB_STYLE);
+    for (int c0 = 0; c0 < C; c0 += w.G) {
+        run_wav2vec(m, audio_dev, c0, (int)std::min<int64_t>(w.G, C - c0), out_w2v_dev, s);
+    }
+    // initial history: encode + quantise an all-zero motion (app/models.py:86-89)
+    launch_enc_input_zero(m->vae_mean, m->vae_std, m->enc_pos, w.enc_in, B, s);
+    run_reencode(m, B, s);
+    const size_t bits_row = (size_t)kNTok * c.code_dim;
+    if (out_hist_bits_dev)
+        HIPCHK(m, hipMemcpy2DAsync(out_hist_bits_dev, (size_t)(maxch + 1) * bits_row, w.hist_bits, bits_row, bits_row, B,
+                                   hipMemcpyDeviceToDevice, s));
+    stage_mark(m, s, PB_VAE);
+    const bool graphs = m->use_graphs && !m->profiling;
+    for (int64_t j = 0; j < maxch; ++j) {
+        const int Bn = Bj[j];
+        // AdaLN table of this chunk index for all blocks + head: SiLU(cond) @ [W_0;...;W_11;W_head]^T
+        linear(m, w.silu_cond + (long)base[j] * kNTok * kCond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, Bn * kNTok, m->ada_n, kCond,
+               ACT_NONE, nullptr, s);
+        stage_mark(m, s, PB_ADA);
+        if (graphs) {
+            auto it = m->graphs.find(Bn);
+            if (it == m->graphs.end()) {
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                HIPCHK(m, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                run_chunk_body(m, Bn, s);
+                HIPCHK(m, hipStreamEndCapture(s, &graph));
+                HIPCHK(m, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                it = m->graphs.emplace(Bn, exec).first;
+            }
+            HIPCHK(m, hipGraphLaunch(it->second, s));
+        } else {
+            run_chunk_body(m, Bn, s);
+        }
+        const size_t mrow = (size_t)100 * c.motion_dim * 4;
+        HIPCHK(m, hipMemcpy2DAsync(out_motion_dev + j * 100 * c.motion_dim, (size_t)out_clip_stride * 4, w.motion_chunk, mrow, mrow, Bn,
+                                   hipMemcpyDeviceToDevice, s));
+        if (out_bits_dev)
+            HIPCHK(m, hipMemcpy2DAsync(out_bits_dev + j * bits_row, (size_t)maxch * bits_row, w.bits, bits_row, bits_row, Bn,
+                                       hipMemcpyDeviceToDevice, s));
+        if (out_hist_bits_dev)
+            HIPCHK(m, hipMemcpy2DAsync(out_hist_bits_dev + (j + 1) * bits_row, (size_t)(maxch + 1) * bits_row, w.hist_bits, bits_row,
+                                       bits_row, Bn, hipMemcpyDeviceToDevice, s));
+    }
+    stage_mark(m, s, PB_OTHER);
+    HIPCHK(m, hipGetLastError());
+    return ARTALK_OK;
+}
+
+int artalk_get_profile(artalk_model* m, double* out, int n) {
+    if (!m || !out || n < 10) return ARTALK_EINVAL;
+    if (!m->profiling || m->marks.size() < 2) return fail(m, ARTALK_ESTATE, "profiling was not enabled for the last artalk_infer");
+    (void)hipSetDevice(m->device);
+    HIPCHK(m, hipStreamSynchronize(m->prof_stream));
+    auto ms = [&](size_t a, size_t b) { float t = 0.f; (void)hipEventElapsedTime(&t, m->ev_pool[a], m->ev_pool[b]); return (double)t; };
+    double r[10] = {0};
+    for (size_t i = 1; i < m->marks.size(); ++i) {
+        const int b = m->marks[i].first;
+        if (b >= 0 && b < 6) r[b] += ms(m->marks[i - 1].second, m->marks[i].second);
+    }
+    r[6] = ms(m->marks.front().second, m->marks.back().second);
+    for (auto& d : m->dom_events) { r[7] += 1.0; r[8] += ms(d.first, d.first + 1); r[9] += d.second; }
+    for (int i = 0; i < 10; ++i) out[i] = r[i];
+    return ARTALK_OK;
+}
+
+int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, void* stream) {
+    if (!m || !in_dev || !out_dev) return ARTALK_EINVAL;
+    if (T < 9) return fail(m, ARTALK_EINVAL, "savgol (mode='interp') needs window_length <= T (T >= 9)");
+    (void)hipSetDevice(m->device);
+    launch_savgol(in_dev, out_dev, T, m->cfg.motion_dim, (hipStream_t)stream);
+    return ARTALK_OK;
+}
+
+// ---------------------------------------------------------------------------------- single-kernel entry points
+int artalk_op_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* gate, const float* R, float* C,
+                   int M, int N, int K, int act, void* stream) {
+    if (!A || !W || !C || K % 32 != 0 || M < 0 || N <= 0) return ARTALK_EINVAL;
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = bias; g.C = C; g.ldc = N; g.gate = gate; g.ldg = N; g.R = R; g.ldr = N;
+    g.M = M; g.N = N; g.K = K; g.act = act;
+    launch_gemm(g, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+}
+
+int artalk_op_layernorm(const float* X, float* Y, const float* w, const float* b, const float* scale, const float* shift, int M,
+                        int D, float eps, int act, void* stream) {
+    if (!X || !Y || (D != 128 && D != 512 && D != 768 && D != 1024)) return ARTALK_EINVAL;
+    LnArgs a;
+    a.X = X; a.ldx = D; a.Y = Y; a.ldy = D; a.w = w; a.b = b; a.scale = scale; a.shift = shift; a.ldm = D; a.M = M; a.D = D;
+    a.eps = eps; a.act = act;
+    launch_layernorm(a, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+}
+
+int artalk_op_attention(const float* Q, const float* K, const float* V, float* O, int B, int H, int HD, int Lq, int Lk, float scale,
+                        int l2norm, const float* qscale, int split, void* stream) {
+    if (!Q || !K || !V || !O || (HD != 64 && HD != 32) || (l2norm && !qscale)) return ARTALK_EINVAL;
+    AttnArgs a;
+    const long D = (long)H * HD;
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = a.ldk = a.ldv = a.ldo = D;
+    a.q_bstride = a.o_bstride = (long)Lq * D; a.k_bstride = a.v_bstride = (long)Lk * D;
+    a.B = B; a.H = H; a.HD = HD; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.l2norm = l2norm; a.qscale = qscale;
+    a.split_q = split; a.split_k = split;
+    launch_attention(a, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+}
+
+int artalk_op_w2v_front(const float* audio, int C, int n, const float* w, const float* bias, const float* lnw, const float* lnb,
+                        float* xnorm_out, float* Y, void* stream) {
+    if (!audio || !xnorm_out || !Y || C <= 0 || n < 10) return ARTALK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<long> off(C);
+    for (int i = 0; i < C; ++i) off[i] = (long)i * n;
+    long* doff = nullptr;
+    if (hipMalloc(&doff, C * sizeof(long)) != hipSuccess) return ARTALK_EHIP;
+    (void)hipMemcpy(doff, off.data(), C * sizeof(long), hipMemcpyHostToDevice);
+    const int T = (n - 10) / 5 + 1;
+    launch_audio_normalize(audio, doff, xnorm_out, C, n, s);
+    launch_conv0(xnorm_out, n, w, bias, lnw, lnb, Y, C, T, T, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(doff);
+    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+}
+
+int artalk_op_pool_silu(const float* X, int C, int T, int D, float* Y, void* stream) {
+    if (!X || !Y || D % 4 != 0) return ARTALK_EINVAL;
+    static const int pn[5] = {1, 5, 25, 50, 100};
+    launch_pool_silu(X, T, T, Y, C, pn, 5, D, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+}
+
+int artalk_op_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fdec, float* msfeat, int B, void* stream) {
+    if (!enc_out || !hist_bits || !prev_fdec || !msfeat || B <= 0) return ARTALK_EINVAL;
+    init_ms_tables();
+    launch_bsq_history(enc_out, hist_bits, prev_fdec, msfeat, B, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+// fp32 GEMM on the gfx950 matrix cores: C = epilogue(A[M,K] * W[N,K]^T).
+//
+// v_mfma_f32_32x32x2_f32 is exact f32 (a k-ordered fmaf chain), which is what lets this path meet the
+// reference's bit-level decisions.  Both operands are K-contiguous (activations
+// row-major, weights in torch's [out,in] layout) so both tiles are staged the same way:
+// global (float4, 128-B row segments) -> registers -> LDS [rows][32+4] (the +4 pad makes the
+// ds_read_b128 fragment reads conflict-free), double-buffered, one barrier per 32-deep K step.
+// Each lane half h holds k in [16h, 16h+16) of the K step: MFMA sums over the two halves, and the
+// k order inside a step is free as long as A and B agree.
+//
+// The same kernel serves the wav2vec2 stride-2 convolutions (channels-last activations make the
+// window of output t a contiguous K=k*512 run at row 2t: a plain GEMM with lda = 2*512) and, with
+// amode=1, the grouped positional convolution (window rows gathered with zero padding).
+#include "common.h"
+
+namespace artalk {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;   // floats; 144-B rows
+
+template <int BM, int BN, int WM, int WN, int AMODE>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_LD = BM * BK / 4 / 256, B_LD = BN * BK / 4 / 256;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1, "tile config");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                     // [2][BM][LDS_LD]
+    float* Bs = smem + 2 * BM * LDS_LD;   // [2][BN][LDS_LD]
+
+    const int tid = threadIdx.x;
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z;
+    const float* __restrict__ A = g.A + z * g.sA;
+    const float* __restrict__ W = g.W + z * g.sW;
+
+    f32x4 ra[A_LD], rb[B_LD];
+    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;   // 8 threads cover one 32-float row segment
+
+    auto gload = [&](int kt) {
+        const int k = kt * BK + lc4;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int gm = m0 + lrow + i * 32;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gm < g.M) {
+                if (AMODE == 0) {
+                    v = *reinterpret_cast<const f32x4*>(A + (long)gm * g.lda + k);
+                } else {
+                    const int c = gm / g.pc_tstride, t = gm - c * g.pc_tstride;
+                    const int tap = k / g.pc_cin, ci = k - tap * g.pc_cin;
+                    const int ts = t + tap - g.pc_pad;
+                    if (ts >= 0 && ts < g.pc_T)
+                        v = *reinterpret_cast<const f32x4*>(A + ((long)c * g.pc_tstride + ts) * g.lda + ci);
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int gn = n0 + lrow + i * 32;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gn < g.N) v = *reinterpret_cast<const f32x4*>(W + (long)gn * g.ldw + k);
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            *reinterpret_cast<f32x4*>(As + (buf * BM + lrow + i * 32) * LDS_LD + lc4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i)
+            *reinterpret_cast<f32x4*>(Bs + (buf * BN + lrow + i * 32) * LDS_LD + lc4) = rb[i];
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = g.K / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* as = As + (buf * BM + wm * (BM / WM) + r) * LDS_LD + h * 16;
+        const float* bs = Bs + (buf * BN + wn * (BN / WN) + r) * LDS_LD + h * 16;
+        f32x4 a[TM][4], b[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[i][q] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_LD + q * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[j][q] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDS_LD + q * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q][e], b[j][q][e], acc[i][j], 0, 0, 0);
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+    const float* __restrict__ bias = g.bias ? g.bias + z * g.sBias : nullptr;
+    float* __restrict__ C = g.C + z * g.sC;
+    const float* R = g.R ? g.R + z * g.sR : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (BN / WN) + j * 32 + r;
+        const bool cok = col < g.N;
+        const float bv = (bias && cok) ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < g.M && cok) {
+                    float v = acc[i][j][e] + bv;
+                    v = apply_act_rt(v, g.act);
+                    if (g.gate) v *= g.gate[(long)map_row(g.gmap, row) * g.ldg + col];
+                    const long crow = map_row(g.cmap, row);
+                    if (R) v += R[crow * g.ldr + col];
+                    C[crow * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_cfg(const GemmArgs& g, hipStream_t s) {
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    const size_t lds = 2 * (BM + BN) * LDS_LD * sizeof(float);
+    dim3 grid(tiles, 1, g.batch);
+    if (g.amode == 0)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, 0>), grid, dim3(256), lds, s, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), lds, s, g);
+}
+
+// 0: 128x128 (the dominant kernel of the path), 1: 128x64, 2: 64x64, 3: 32x128
+int gemm_config(const GemmArgs& g) {
+    const long tm128 = (g.M + 127) / 128;
+    if (g.N <= 64 && tm128 * g.batch >= 256) return 1;
+    const long t128 = tm128 * ((g.N + 127) / 128) * g.batch;
+    if (t128 >= 384) return 0;
+    if (g.M > 32) return 2;
+    return 3;
+}
+
+void launch_gemm(const GemmArgs& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return;
+    switch (gemm_config(g)) {
+        case 0: launch_cfg<128, 128, 2, 2>(g, s); break;
+        case 1: launch_cfg<128, 64, 2, 2>(g, s); break;
+        case 2: launch_cfg<64, 64, 2, 2>(g, s); break;
+        default: launch_cfg<32, 128, 1, 4>(g, s); break;
+    }
+}
+
+}  // namespace artalk

@@ -40,6 +40,7 @@ struct GemmArgs {
     int amode = 0; int pc_T = 0, pc_tstride = 0, pc_pad = 0, pc_cin = 0;
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);
+int gemm_config(const GemmArgs& g);   // 0: 128x128 tile (dominant kernel), 1: 128x64, 2: 64x64, 3: 32x128
 // Average kernel time helper for benches: FLOPs of one launch
 static inline double gemm_flops(const GemmArgs& g) { return 2.0 * g.M * (double)g.N * g.K * g.batch; }
 
@@ -79,12 +80,11 @@ void launch_pool_silu(const float* X, int x_tstride, int T, float* Y, int n_chun
                       int D, hipStream_t s);
 
 // ---- AR / VAE glue ----
-struct MsTables;   // device-resident interpolation tables (built once, bsq.hip)
-// logits [B*pn, 64] -> bits of level p (written into bits[b, off..off+pn, 32]); fhat[b] += up(h_p) (p < 4)
-void launch_ar_bits(const float* logits, uint8_t* bits, float* fhat, int B, int level, hipStream_t s);
-// x_next[b*pn' + i, :] = We * area(fhat[b] -> pn')[i] + be + lvlpos[off' + i]   (input tokens of level p+1)
-void launch_ar_next_embed(const float* fhat, const float* We, const float* be, const float* lvlpos, float* x,
-                          int B, int next_level, hipStream_t s);
+// level p: logits [B*pn, 64] -> bits[b, off..off+pn, 32]; fhat[b] += up(h_p); nextfeat[b, :pn[p+1], 32] = area(fhat) (p < 4)
+void launch_ar_bits_next(const float* logits, uint8_t* bits, float* fhat, float* nextfeat, int B, int level, hipStream_t s);
+// X[b*xrows + xoff + i, :] = We*feat[b,i,:] + be + pos[i,:] (i < n); if style_cond: X[b*xrows, :] = style_cond[b] + pos0
+void launch_vq_embed(const float* feat, int n, const float* We, const float* be, const float* pos, float* X, int xrows,
+                     int xoff, const float* style_cond, const float* pos0, int B, hipStream_t s);
 // x0[b, :] = style_cond[b] + lvlpos[0]; also zeroes fhat
 void launch_ar_begin(const float* style_cond, const float* lvlpos, float* x0, float* fhat, int B, hipStream_t s);
 // decoder input rows [b*200 + t]: t<100: prev_fdec[b,t] + dpos[t]; t>=100: fhat[b,t-100] + h(bits level 4)[t-100] + dpos[t]
@@ -97,9 +97,6 @@ void launch_dec_finish(const float* dec /*[B*200,106]*/, const float* mean, cons
 void launch_enc_input_zero(const float* mean, const float* stdv, const float* epos, float* E, int B, hipStream_t s);
 // multi-scale BSQ of enc_out [B*100,32] -> hist bits [B,181,32], prev_fdec [B,100,32], ms feats [B,180,32]
 void launch_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fdec, float* msfeat, int B, hipStream_t s);
-// prev_in[b*181 + 0] = style_cond[b] + ppos[0]; prev_in[b*181 + 1 + i] = We*msfeat[b,i] + be + ppos[1+i]
-void launch_prev_embed(const float* style_cond, const float* msfeat, const float* We, const float* be,
-                       const float* ppos, float* prev_in, int B, hipStream_t s);
 // style: X[b*50+t, 0:128] = (m - mean)/std (cols >= 106 zero)
 void launch_style_input(const float* motion, const float* mean, const float* stdv, float* X, int B, hipStream_t s);
 // style_cond[b] = has_style[b] ? 1.1*(Ws*mean_t(feat[b]) + bs) - 0.1*null : null

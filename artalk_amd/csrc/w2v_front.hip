@@ -1,0 +1,139 @@
+// wav2vec2 front-end kernels (HBM-bound byte movers) and the multi-scale audio pooling.
+//   audio_normalize  app/modules/wav2vec.py:22-27   per-chunk (x-mean)/(std_unbiased+1e-6)
+//   conv0            hf:275-299 layer 0             Conv1d(1->512,k=10,s=5)+bias -> LN(512) -> GELU(erf)
+//   pool_silu        app/models.py:94-95            area pooling 199 -> {1,5,25,50,100}; SiLU of app/transformer.py:25
+#include "common.h"
+
+namespace artalk {
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void audio_normalize_kernel(const float* __restrict__ audio, const long* __restrict__ src_off,
+                                                               float* __restrict__ xn, int n) {
+    __shared__ double red[16];
+    __shared__ float stat[2];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* x = audio + src_off[c];
+    double s = 0.0;
+    for (int i = tid; i < n; i += 1024) s += (double)x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        stat[0] = (float)(t / n);
+    }
+    __syncthreads();
+    const double mean = (double)stat[0];
+    double q = 0.0;
+    for (int i = tid; i < n; i += 1024) { const double d = (double)x[i] - mean; q += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    __syncthreads();
+    if (lane == 0) red[wv] = q;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        stat[1] = (float)sqrt(t / (n - 1));
+    }
+    __syncthreads();
+    const float m = stat[0], den = stat[1] + 1e-6f;
+    float* y = xn + (long)c * n;
+    for (int i = tid; i < n; i += 1024) y[i] = (x[i] - m) / den;
+}
+
+void launch_audio_normalize(const float* audio, const long* src_off, float* xnorm, int n_chunks, int n, hipStream_t s) {
+    if (n_chunks <= 0) return;
+    hipLaunchKernelGGL(audio_normalize_kernel, dim3(n_chunks), dim3(1024), 0, s, audio, src_off, xnorm, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One wavefront per output frame: lane l owns channels 4l..4l+3 and 256+4l..256+4l+3 (two 1-KiB
+// coalesced stores per row); the 80 filter taps live in registers; LN statistics by wave butterflies.
+// 20 bytes of audio in, 2 KiB out per frame: store-bandwidth bound.
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn, int n, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                    const float* __restrict__ lnb, float* __restrict__ Y, int T, int row_stride) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.y;
+    int ch[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ch[j] = (j >> 2) * 256 + lane * 4 + (j & 3);
+    float wt[8][10], bs[8], gw[8], gb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) wt[j][k] = w[ch[j] * 10 + k];
+        bs[j] = bias[ch[j]]; gw[j] = lnw[ch[j]]; gb[j] = lnb[ch[j]];
+    }
+    const float* x = xn + (long)c * n;
+    for (int t = blockIdx.x * 4 + wv; t < T; t += gridDim.x * 4) {
+        const int idx = min(5 * t + (lane & 15), n - 1);
+        const float xv = x[idx];
+        float xs[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) xs[k] = __shfl(xv, k, 64);
+        float v[8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float acc = bs[j];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) acc = fmaf(wt[j][k], xs[k], acc);
+            v[j] = acc; s += acc;
+        }
+        const float mean = wave_sum(s) * (1.0f / 512.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 512.0f) + 1e-5f);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = gelu_erf((v[j] - mean) * rstd * gw[j] + gb[j]);
+        float* y = Y + ((long)c * row_stride + t) * 512;
+        f32x4 lo = {o[0], o[1], o[2], o[3]}, hi = {o[4], o[5], o[6], o[7]};
+        *reinterpret_cast<f32x4*>(y + lane * 4) = lo;
+        *reinterpret_cast<f32x4*>(y + 256 + lane * 4) = hi;
+    }
+}
+
+void launch_conv0(const float* xnorm, int n, const float* w, const float* bias, const float* lnw, const float* lnb,
+                  float* Y, int n_chunks, int T, int row_stride, hipStream_t s) {
+    if (n_chunks <= 0) return;
+    hipLaunchKernelGGL(conv0_kernel, dim3(128, n_chunks), dim3(256), 0, s, xnorm, n, w, bias, lnw, lnb, Y, T, row_stride);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct PoolLevels { int n; int pn[8]; };
+
+__global__ __launch_bounds__(256) void pool_silu_kernel(const float* __restrict__ X, int x_tstride, int T, float* __restrict__ Y,
+                                                        PoolLevels lv, int ntok, int D) {
+    const int tok = blockIdx.x, c = blockIdx.y;
+    int p = 0, i = tok;
+    while (i >= lv.pn[p]) { i -= lv.pn[p]; ++p; }
+    const int pn = lv.pn[p];
+    const int t0 = (i * T) / pn, t1 = ((i + 1) * T + pn - 1) / pn;   // adaptive_avg_pool1d bins
+    const float inv = (float)(t1 - t0);
+    for (int d = threadIdx.x * 4; d < D; d += 256 * 4) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int t = t0; t < t1; ++t) s += *reinterpret_cast<const f32x4*>(X + ((long)c * x_tstride + t) * D + d);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = silu(s[e] / inv);
+        *reinterpret_cast<f32x4*>(Y + ((long)c * ntok + tok) * D + d) = o;
+    }
+}
+
+void launch_pool_silu(const float* X, int x_tstride, int T, float* Y, int n_chunks, const int* patch_nums, int n_lvls, int D,
+                      hipStream_t s) {
+    if (n_chunks <= 0) return;
+    PoolLevels lv;
+    lv.n = n_lvls;
+    int ntok = 0;
+    for (int i = 0; i < 8; ++i) { lv.pn[i] = i < n_lvls ? patch_nums[i] : 1 << 30; if (i < n_lvls) ntok += patch_nums[i]; }
+    hipLaunchKernelGGL(pool_silu_kernel, dim3(ntok, n_chunks), dim3(256), 0, s, X, x_tstride, T, Y, lv, ntok, D);
+}
+
+}  // namespace artalk

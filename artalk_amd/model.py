@@ -1,0 +1,257 @@
+"""Host-side mirror of the reference's ``BitwiseARModel`` (``app/models.py:13-148``) over the C ABI.
+
+Same call surface as the object the reference stores in ``ARTAvatarInferEngine.ARTalk``
+(``inference.py:27``): ``BitwiseARModel(configs).eval().to(device)``, ``load_state_dict(ckpt, strict=True)``,
+``inference(batch, with_gtmotion=False) -> (1, T, 106)`` and ``basic_vae.get_flame_verts(...)``; same exception
+types (``AssertionError`` for batch != 1, ``ValueError`` for an unknown audio encoder, ``RuntimeError`` from a
+strict ``load_state_dict`` with missing/unexpected keys).  ``inference_batch`` is the data-parallel extension:
+B independent batch-1 runs in one call (all ops of the path are row independent).
+
+PyTorch is used for device memory and streams only; all arithmetic runs in ``libartalk_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import capi
+from .config import ARTalkConfig
+
+
+class _BasicVAE:
+    """What the renderer side touches on ``model.basic_vae`` (reference ``inference.py:69``)."""
+
+    def __init__(self, cfg: ARTalkConfig):
+        self.motion_dim = cfg.motion_dim
+        self.code_dim = cfg.code_dim
+        self.patch_nums = list(cfg.patch_nums)
+
+    def get_flame_verts(self, flame_model, shape_params, motion_params, with_global=False):
+        # app/modules/bitwise_vae.py:43-57: pure pass-through to the caller's FLAME model
+        exp_code, pose_code = motion_params[..., :100], motion_params[..., 100:]
+        if not with_global:
+            pose_code = torch.cat([torch.zeros_like(pose_code[..., :3]), pose_code[..., 3:]], dim=-1)
+        if shape_params.dim() == 2:
+            return flame_model(shape_params=shape_params, expression_params=exp_code, pose_params=pose_code)
+        if shape_params.dim() == 3:
+            verts = [flame_model(shape_params=shape_params[b], expression_params=exp_code[b], pose_params=pose_code[b])
+                     for b in range(shape_params.shape[0])]
+            return torch.stack(verts, dim=0)
+        raise ValueError("Invalid shape of shape_params: {}".format(shape_params.shape))
+
+
+class BitwiseARModel:
+    def __init__(self, model_cfg=None, w2v_config: Optional[dict] = None, **kwargs):
+        if isinstance(model_cfg, ARTalkConfig):
+            self.cfg = model_cfg
+        else:
+            self.cfg = ARTalkConfig.from_reference_dict(model_cfg, w2v=w2v_config)   # ValueError for a bad AUDIO_ENCODER
+        self.basic_vae = _BasicVAE(self.cfg)
+        self.patch_nums = self.basic_vae.patch_nums
+        self.prev_ratio = self.cfg.prev_ratio
+        self.attn_depth = self.cfg.ar_depth
+        self.audio_feature_dim = self.cfg.cond_dim
+        self._device = torch.device("cuda", 0)
+        self._h = None
+        self._loaded = False
+        self._reserved = (0, 0)
+        self._stream = None      # dedicated HIP stream (hipGraph capture is not allowed on the legacy default stream)
+        self.last_aux = {}
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def eval(self):
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("artalk_amd runs on an AMD GPU only (device must be 'cuda[:i]'); there is no CPU path")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        if self._h is not None and device != self._device:
+            raise RuntimeError("weights are already resident on {}; create a new model for another GPU".format(self._device))
+        self._device = device
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    @property
+    def device(self):
+        return self._device
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                capi.lib().artalk_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def _err(self):
+        return capi.lib().artalk_last_error(self._h).decode()
+
+    def load_state_dict(self, state_dict, strict=True):
+        """``load_state_dict(ckpt, strict=True)`` of reference ``inference.py:28`` (814-entry manifest)."""
+        assert strict, "only strict=True (what the reference uses) is supported"
+        L = capi.lib()
+        if self._h is None:
+            h = C.c_void_p()
+            cs = capi.config_struct(self.cfg)
+            rc = L.artalk_create(self._device.index or 0, C.byref(cs), C.byref(h))
+            if rc != capi.OK:
+                raise RuntimeError("artalk_create failed: " + L.artalk_last_error(None).decode())
+            self._h = h
+        errors = []
+        for key, val in state_dict.items():
+            t = val.detach().cpu() if isinstance(val, torch.Tensor) else torch.from_numpy(np.asarray(val))
+            if t.dtype == torch.int64:
+                dt = capi.DTYPE_I64
+            else:
+                t = t.to(torch.float32)
+                dt = capi.DTYPE_F32
+            t = t.contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            rc = L.artalk_set_tensor(self._h, key.encode(), C.c_void_p(t.data_ptr()), dt, t.dim(), shape)
+            if rc != capi.OK:
+                errors.append(self._err())
+                if rc == capi.EHIP:
+                    break
+        rc = L.artalk_finalize_weights(self._h) if not errors else capi.EINVAL
+        if rc != capi.OK and not errors:
+            errors.append(self._err())
+        if errors:
+            raise RuntimeError("Error(s) in loading state_dict for BitwiseARModel:\n\t" + "\n\t".join(errors[:12]))
+        self._loaded = True
+        return self
+
+    def reserve(self, max_batch: int, max_total_chunks: int):
+        """Pre-allocate the workspace (otherwise sized by the first ``inference`` call)."""
+        rc = capi.lib().artalk_reserve(self._h, int(max_batch), int(max_total_chunks))
+        if rc != capi.OK:
+            raise RuntimeError("artalk_reserve failed: " + self._err())
+        self._reserved = (int(max_batch), int(max_total_chunks))
+
+    def workspace_bytes(self):
+        return int(capi.lib().artalk_workspace_bytes(self._h))
+
+    def weight_bytes(self):
+        return int(capi.lib().artalk_weight_bytes(self._h))
+
+    def set_profiling(self, on: bool):
+        capi.lib().artalk_set_profiling(self._h, int(bool(on)))
+
+    def set_graphs(self, on: bool):
+        capi.lib().artalk_set_graphs(self._h, int(bool(on)))
+
+    def get_profile(self):
+        out = (C.c_double * 10)()
+        rc = capi.lib().artalk_get_profile(self._h, out, 10)
+        if rc != capi.OK:
+            raise RuntimeError("artalk_get_profile failed: " + self._err())
+        keys = ["style_ms", "w2v_conv_ms", "w2v_encoder_ms", "ada_ms", "ar_ms", "vae_ms", "total_ms",
+                "dom_launches", "dom_ms", "dom_flop"]
+        return dict(zip(keys, list(out)))
+
+    # ------------------------------------------------------------------ geometry of app/models.py:66,78-80
+    def seq_length(self, n_samples: int) -> int:
+        return math.ceil(n_samples / 16000 * 25.0)
+
+    def n_chunks(self, n_samples: int) -> int:
+        return math.ceil(self.seq_length(n_samples) / self.patch_nums[-1])
+
+    # ------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def inference(self, batch, with_gtmotion=False):
+        """Reference ``BitwiseARModel.inference`` (app/models.py:62-121)."""
+        batch_size = batch["audio"].shape[0]
+        assert batch_size == 1, "Only support batch size 1 for inference."
+        style = batch.get("style_motion", None)
+        out = self.inference_batch([batch["audio"][0]], [style[0] if style is not None else None])[0][None]
+        if with_gtmotion:
+            min_length = min(batch["motion"].shape[1], out.shape[1])
+            shape_code = batch["shape"].expand(-1, min_length, -1)
+            return out[:, :min_length], batch["motion"][:, :min_length], shape_code
+        return out
+
+    @torch.no_grad()
+    def inference_batch(self, audios: Sequence[torch.Tensor], style_motions: Optional[Sequence[Optional[torch.Tensor]]] = None,
+                        return_aux: bool = False) -> List[torch.Tensor]:
+        """B independent clips -> list of ``(ceil(N_b/640), 106)`` float32 tensors on ``self.device``.
+
+        With ``return_aux`` the per-chunk bits, history bits and wav2vec2 features of the call are kept in
+        ``self.last_aux`` (used by the parity tests).
+        """
+        if not self._loaded:
+            raise RuntimeError("load_state_dict must be called before inference")
+        L = capi.lib()
+        B = len(audios)
+        if B == 0:
+            return []
+        dev = self._device
+        n_samples = [int(a.shape[-1]) for a in audios]
+        for a in audios:
+            if a.dim() != 1 or a.shape[0] == 0:
+                raise ValueError("each clip must be a non-empty 1-D float tensor of 16 kHz samples")
+        seq = [self.seq_length(n) for n in n_samples]
+        nch = [self.n_chunks(n) for n in n_samples]
+        order = sorted(range(B), key=lambda i: -nch[i])          # stable: ragged batches become dense prefixes
+        maxch, total = nch[order[0]], sum(nch)
+        spc = self.cfg.samples_per_chunk
+        with torch.cuda.device(dev):
+            audio_pad = torch.zeros(B, maxch * spc, dtype=torch.float32, device=dev)   # zero padding of app/models.py:81-85
+            for pos, i in enumerate(order):
+                audio_pad[pos, :n_samples[i]] = audios[i].to(device=dev, dtype=torch.float32, non_blocking=True)
+            style_t, has = None, None
+            if style_motions is not None and any(s is not None for s in style_motions):
+                style_t = torch.zeros(B, self.cfg.style_len, self.cfg.motion_dim, dtype=torch.float32, device=dev)
+                has = (C.c_uint8 * B)()
+                for pos, i in enumerate(order):
+                    s = style_motions[i]
+                    if s is not None:
+                        assert tuple(s.shape) == (self.cfg.style_len, self.cfg.motion_dim), f"Invalid style_motion shape: {tuple(s.shape)}."
+                        style_t[pos] = s.to(device=dev, dtype=torch.float32)
+                        has[pos] = 1
+            out = torch.empty(B, maxch * 100, self.cfg.motion_dim, dtype=torch.float32, device=dev)
+            bits = hist = w2v = None
+            if return_aux:
+                bits = torch.zeros(B, maxch, 181, 32, dtype=torch.uint8, device=dev)
+                hist = torch.zeros(B, maxch + 1, 181, 32, dtype=torch.uint8, device=dev)
+                w2v = torch.zeros(total, 199, self.cfg.cond_dim, dtype=torch.float32, device=dev)
+            nch_sorted = (C.c_int64 * B)(*[nch[i] for i in order])
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=dev)
+            caller = torch.cuda.current_stream()
+            self._stream.wait_stream(caller)
+            rc = L.artalk_infer(self._h, capi.ptr(audio_pad), audio_pad.stride(0), nch_sorted, B, capi.ptr(style_t),
+                                C.cast(has, C.c_void_p) if has is not None else None, capi.ptr(out), out.stride(0),
+                                capi.ptr(bits), capi.ptr(hist), capi.ptr(w2v), C.c_void_p(self._stream.cuda_stream))
+            caller.wait_stream(self._stream)
+            for t in (audio_pad, style_t, out, bits, hist, w2v):
+                if t is not None:
+                    t.record_stream(self._stream)
+            if rc != capi.OK:
+                raise RuntimeError("artalk_infer failed ({}): {}".format(rc, self._err()))
+            results: List[Optional[torch.Tensor]] = [None] * B
+            for pos, i in enumerate(order):
+                results[i] = out[pos, :seq[i]]                               # truncate, app/models.py:115
+            if return_aux:
+                # wav2vec2 features come chunk-index major over the sorted clips
+                w2v_idx = {}
+                k = 0
+                for j in range(maxch):
+                    for pos, i in enumerate(order):
+                        if nch[i] > j:
+                            w2v_idx[(i, j)] = k
+                            k += 1
+                self.last_aux = {
+                    "bits": [bits[pos, :nch[i]] for pos, i in sorted(enumerate(order), key=lambda t: t[1])],
+                    "hist_bits": [hist[pos, :nch[i] + 1] for pos, i in sorted(enumerate(order), key=lambda t: t[1])],
+                    "w2v": w2v, "w2v_index": w2v_idx, "order": order, "n_chunks": nch,
+                }
+        return results

@@ -1,0 +1,122 @@
+/* C ABI of libartalk_hip.so: the MI355X (gfx950) implementation of ARTalk's audio->motion path.
+ *
+ * The reference has no FFI layer; its operator boundary is the Python object stored in
+ * ARTAvatarInferEngine.ARTalk (reference inference.py:27).  The entry points below are what a binding
+ * for that object needs, one per call the reference makes across the boundary:
+ *
+ *   artalk_create            <- BitwiseARModel(configs).eval().to(device)        inference.py:27, app/models.py:14-56
+ *   artalk_set_tensor        <- one state_dict entry of load_state_dict(strict)  inference.py:28
+ *   artalk_finalize_weights  <- end of load_state_dict(strict=True): missing keys are an error
+ *   artalk_infer             <- BitwiseARModel.inference(batch)                  inference.py:50, app/models.py:62-121
+ *                               (batched: B independent batch-1 runs; the reference asserts B==1, app/models.py:65)
+ *   artalk_savgol            <- ARTAvatarInferEngine.smooth_motion_savgol        inference.py:89-95
+ *   artalk_destroy           <- object lifetime
+ *
+ * Conventions: plain pointers and sizes only; all *_dev pointers are device memory on the model's GPU;
+ * every call returns 0 on success or a negative ARTALK_E* code (text via artalk_last_error); the caller
+ * owns every buffer it passes; the library owns weights and workspace; one model per GPU, calls on one
+ * model are not thread-safe; work is enqueued on the hipStream_t passed as `stream` (NULL = default
+ * stream) and artalk_infer returns without synchronising.
+ *
+ * The artalk_op_* entry points expose single kernels so that tests can check each one against the CPU
+ * oracle through this same ABI; they are not needed by a binding.
+ */
+#ifndef ARTALK_HIP_H
+#define ARTALK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARTALK_OK 0
+#define ARTALK_EINVAL (-1)      /* bad argument / shape mismatch                      */
+#define ARTALK_EKEY (-2)        /* unknown state_dict key (strict=True)               */
+#define ARTALK_EMISSING (-3)    /* finalize with keys missing (strict=True)           */
+#define ARTALK_EHIP (-4)        /* HIP runtime error                                  */
+#define ARTALK_ESTATE (-5)      /* call order (infer before finalize, ...)            */
+#define ARTALK_ECAPACITY (-6)   /* batch larger than the reserved workspace           */
+
+#define ARTALK_DTYPE_F32 0
+#define ARTALK_DTYPE_I64 1
+
+typedef struct artalk_model artalk_model;
+
+/* assets/config.json + the XLS-R-300M hyper-parameters (reference app/models.py:25) */
+typedef struct artalk_config {
+    int32_t ar_depth, ar_heads;                 /* AR_CONFIG.T_DEPTH, T_NUM_HEADS (PREV_RATIO must be 1)  */
+    int32_t vae_depth, vae_heads, vae_hidden;   /* VAE_CONFIG.T_DEPTH, T_NUM_HEADS, T_HIDDEN_DIM          */
+    int32_t code_dim, motion_dim;               /* 32, 106                                                */
+    int32_t n_levels; int32_t patch_nums[8];    /* 5; 1,5,25,50,100                                       */
+    int32_t w2v_layers, w2v_hidden, w2v_heads, w2v_ffn;
+    int32_t w2v_n_conv; int32_t w2v_conv_kernel[8]; int32_t w2v_conv_stride[8]; int32_t w2v_conv_dim;
+    int32_t w2v_pos_kernel, w2v_pos_groups;
+    float w2v_ln_eps;
+    int32_t style_dim, style_heads, style_layers, style_ffn, style_len;
+} artalk_config;
+
+int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out);
+void artalk_destroy(artalk_model* m);
+const char* artalk_last_error(const artalk_model* m);   /* m may be NULL: error of the last failed create */
+
+/* One call per state_dict entry, host memory, reference key names. */
+int artalk_set_tensor(artalk_model* m, const char* key, const void* host_ptr, int dtype, int ndim, const int64_t* shape);
+/* Folds weight-norm, re-lays out conv weights, builds fused tables.  ARTALK_EMISSING lists missing keys in last_error. */
+int artalk_finalize_weights(artalk_model* m);
+
+/* Allocate workspace for up to max_batch clips and max_total_chunks 4-second chunks per artalk_infer call. */
+int artalk_reserve(artalk_model* m, int max_batch, int max_total_chunks);
+int64_t artalk_workspace_bytes(const artalk_model* m);
+int64_t artalk_weight_bytes(const artalk_model* m);
+
+/* Audio -> FLAME codes for B independent clips.
+ *   audio_dev        [B][audio_clip_stride] f32, 16 kHz mono; clip b holds n_chunks[b]*64000 samples, zero padded
+ *                    by the caller exactly as app/models.py:78-85 pads.
+ *   n_chunks         host, [B], must be non-increasing (the host sorts clips; ragged batches stay dense prefixes).
+ *   style_motion_dev [B][50][106] f32 or NULL; has_style host [B] (NULL = none): app/models.py:67-73.
+ *   out_motion_dev   [B][out_clip_stride] f32, receives n_chunks[b]*100 rows of 106 per clip (caller truncates
+ *                    to ceil(N/640) rows, app/models.py:115).
+ *   out_bits_dev     optional [B][max_chunks][181][32] u8: the 0/1 decisions of app/models.py:104 (last scale step).
+ *   out_hist_bits_dev optional [B][max_chunks+1][181][32] u8: history bits of bitwise_vae.py:78-93 (index 0 = initial).
+ *   out_w2v_dev      optional [total_chunks][199][1024] f32 wav2vec2 features, chunk order (chunk index major, clip minor).
+ */
+int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_stride, const int64_t* n_chunks, int B,
+                 const float* style_motion_dev, const uint8_t* has_style, float* out_motion_dev, int64_t out_clip_stride,
+                 uint8_t* out_bits_dev, uint8_t* out_hist_bits_dev, float* out_w2v_dev, void* stream);
+
+/* Savitzky-Golay smoothing of inference.py:89-95 on the device: in/out [T][106] f32, T >= 9. */
+int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, void* stream);
+
+/* Per-call stage timing (HIP events on the call's stream).  enable=1 makes artalk_infer record events;
+ * artalk_get_profile synchronises them and returns milliseconds / counters of the LAST artalk_infer:
+ *   out[0] style  out[1] wav2vec2 conv stack  out[2] wav2vec2 encoder  out[3] AdaLN table GEMM
+ *   out[4] AR scale steps  out[5] VAE decode+re-encode  out[6] total
+ *   out[7] launches of the dominant kernel (128x128 fp32 MFMA GEMM)  out[8] their summed ms  out[9] their summed FLOP */
+int artalk_set_profiling(artalk_model* m, int enable);
+int artalk_get_profile(artalk_model* m, double* out, int n);
+/* Replay the AR/VAE part from hipGraphs captured per active-batch size (default 1 = on). */
+int artalk_set_graphs(artalk_model* m, int enable);
+
+/* ---- single-kernel entry points for the parity tests (device pointers, row-major f32) ---- */
+/* C[M,N] = R + gate * act(A[M,K] W[N,K]^T + bias); act: 0 none, 1 gelu(erf), 2 gelu(tanh), 3 leaky_relu(0.2). K % 32 == 0 */
+int artalk_op_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* gate, const float* R,
+                   float* C, int M, int N, int K, int act, void* stream);
+/* y = LN(x)[*w+b][*(1+scale)+shift][act], D in {128,512,768,1024} */
+int artalk_op_layernorm(const float* X, float* Y, const float* w, const float* b, const float* scale, const float* shift,
+                        int M, int D, float eps, int act, void* stream);
+/* Q,K,V,O: [B][L][H*HD] contiguous; l2norm!=0 -> q,k normalised, q *= qscale[h]; split: queries<split see keys<split */
+int artalk_op_attention(const float* Q, const float* K, const float* V, float* O, int B, int H, int HD, int Lq, int Lk,
+                        float scale, int l2norm, const float* qscale, int split, void* stream);
+/* audio [C][n] -> normalised -> conv0+LN+GELU: Y [C][T][512], T = (n-10)/5+1 */
+int artalk_op_w2v_front(const float* audio, int C, int n, const float* w, const float* bias, const float* lnw,
+                        const float* lnb, float* xnorm_out, float* Y, void* stream);
+/* X [C][T][D] -> Y [C][181][D]: area pooling to {1,5,25,50,100} then SiLU */
+int artalk_op_pool_silu(const float* X, int C, int T, int D, float* Y, void* stream);
+/* enc_out [B][100][32] -> hist_bits [B][181][32] u8, prev_fdec [B][100][32], msfeat [B][180][32] */
+int artalk_op_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fdec, float* msfeat, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARTALK_HIP_H */

@@ -1,0 +1,208 @@
+"""Each HIP kernel, called through the C ABI (artalk_op_*), against torch fp32/fp64 CPU math of the same op.
+
+Tolerances: the kernels are exact-fp32 (MFMA f32 is an fmaf chain), so differences to a float64 reference are
+accumulation-order rounding only: |err| <= 2e-5 * sum|a*b| scale for GEMMs, 2e-5 absolute for O(1) outputs.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from artalk_amd import capi
+    return capi, capi.lib()
+
+
+def _dev(t):
+    return t.contiguous().cuda()
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+@pytest.mark.parametrize("M,N,K,act,use_bias,use_gate,use_res", [
+    (1000, 512, 1536, 0, True, False, False),     # conv-as-GEMM shape, 128x128 tiles
+    (2000, 1024, 1024, 1, True, False, True),     # gelu(erf) + residual
+    (333, 768, 3072, 2, True, True, True),        # ragged M, gelu(tanh), gate, residual; 64x64 tiles
+    (32, 2304, 768, 0, True, False, False),       # tiny M: 32x128 tiles
+    (5, 64, 768, 0, True, False, False),          # logits head shape
+    (200, 106, 512, 0, True, False, False),       # N not a multiple of anything
+    (6400, 512, 32, 3, True, False, False),       # K = 32, leaky relu
+    (40000, 64, 1024, 0, False, False, False),    # 128x64 tiles
+])
+def test_gemm(M, N, K, act, use_bias, use_gate, use_res):
+    capi, L = _lib()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g) if use_bias else None
+    gate = torch.randn(M, N, generator=g) if use_gate else None
+    R = torch.randn(M, N, generator=g) if use_res else None
+    ref = A.double() @ W.double().t()
+    if bias is not None:
+        ref = ref + bias.double()
+    ref = ref.float()
+    if act == 1:
+        ref = F.gelu(ref)
+    elif act == 2:
+        ref = F.gelu(ref, approximate="tanh")
+    elif act == 3:
+        ref = F.leaky_relu(ref, 0.2)
+    if gate is not None:
+        ref = ref * gate
+    if R is not None:
+        ref = ref + R
+    dA, dW = _dev(A), _dev(W)
+    db, dg, dR = (_dev(x) if x is not None else None for x in (bias, gate, R))
+    out = torch.full((M, N), float("nan"), device="cuda")
+    rc = L.artalk_op_gemm(_p(dA), K, _p(dW), _p(db), _p(dg), _p(dR), _p(out), M, N, K, act, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 3e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_gemm_exact_integers():
+    """A = I-like and asymmetric small integers: the MFMA lane maps (no row/col swap) are exact in fp32."""
+    capi, L = _lib()
+    M, N, K = 160, 192, 64
+    A = torch.randint(-3, 4, (M, K)).float()
+    W = (torch.arange(N * K).reshape(N, K) % 7 - 3).float()
+    ref = A @ W.t()
+    out = torch.empty(M, N, device="cuda")
+    dA, dW = _dev(A), _dev(W)
+    assert L.artalk_op_gemm(_p(dA), K, _p(dW), None, None, None, _p(out), M, N, K, 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("D,affine,mod,act,eps", [(512, True, False, 1, 1e-5), (1024, True, False, 0, 1e-5),
+                                                    (768, False, True, 0, 1e-6), (128, True, False, 0, 1e-5)])
+def test_layernorm(D, affine, mod, act, eps):
+    capi, L = _lib()
+    g = torch.Generator().manual_seed(D)
+    M = 777
+    X = torch.randn(M, D, generator=g) * 2 + 0.3
+    w = torch.randn(D, generator=g) if affine else None
+    b = torch.randn(D, generator=g) if affine else None
+    sc = torch.randn(M, D, generator=g) if mod else None
+    sh = torch.randn(M, D, generator=g) if mod else None
+    ref = F.layer_norm(X.double(), (D,), w.double() if affine else None, b.double() if affine else None, eps).float()
+    if mod:
+        ref = ref * (sc + 1) + sh
+    if act == 1:
+        ref = F.gelu(ref)
+    dX = _dev(X)
+    dw, db, dsc, dsh = (_dev(x) if x is not None else None for x in (w, b, sc, sh))
+    out = torch.empty(M, D, device="cuda")
+    assert L.artalk_op_layernorm(_p(dX), _p(out), _p(dw), _p(db), _p(dsc), _p(dsh), M, D, eps, act, None) == 0
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("B,H,HD,Lq,Lk,l2norm,split", [
+    (3, 16, 64, 199, 199, 0, 0),      # wav2vec2 encoder
+    (2, 12, 64, 25, 212, 1, 0),       # AR step 2 with KV cache: 181 history + 6 + 25 keys
+    (2, 12, 64, 1, 182, 1, 0),        # AR step 0
+    (2, 12, 64, 100, 362, 1, 0),      # AR step 4
+    (2, 8, 64, 200, 200, 0, 100),     # VAE decoder mask
+    (2, 8, 64, 100, 100, 0, 0),       # VAE encoder
+    (3, 4, 32, 50, 50, 0, 0),         # style encoder
+])
+def test_attention(B, H, HD, Lq, Lk, l2norm, split):
+    capi, L = _lib()
+    g = torch.Generator().manual_seed(Lq * 1000 + Lk)
+    D = H * HD
+    Q = torch.randn(B, Lq, D, generator=g)
+    K = torch.randn(B, Lk, D, generator=g)
+    V = torch.randn(B, Lk, D, generator=g)
+    qs = (torch.rand(H, generator=g) * 4 + 1) if l2norm else None
+    scale = 1.0 if l2norm else (512 ** -0.5 if split or (H == 8) else HD ** -0.5)
+    q = Q.view(B, Lq, H, HD).transpose(1, 2).double()
+    k = K.view(B, Lk, H, HD).transpose(1, 2).double()
+    v = V.view(B, Lk, H, HD).transpose(1, 2).double()
+    if l2norm:
+        q = F.normalize(q, dim=-1) * qs.double().view(1, H, 1, 1)
+        k = F.normalize(k, dim=-1)
+    s = q @ k.transpose(-1, -2) * scale
+    if split:
+        mask = torch.zeros(Lq, Lk, dtype=torch.double)
+        mask[:split, split:] = -float("inf")
+        s = s + mask
+    ref = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, Lq, D).float()
+    dQ, dK, dV = _dev(Q), _dev(K), _dev(V)
+    dqs = _dev(qs) if qs is not None else None
+    out = torch.full((B, Lq, D), float("nan"), device="cuda")
+    assert L.artalk_op_attention(_p(dQ), _p(dK), _p(dV), _p(out), B, H, HD, Lq, Lk, scale, l2norm, _p(dqs), split, None) == 0
+    torch.cuda.synchronize()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 2e-5, err
+
+
+def test_w2v_front():
+    """audio normalisation + conv0 + LN + GELU vs torch (reference ops: wav2vec.py:22-27, hf:291-299)."""
+    capi, L = _lib()
+    g = torch.Generator().manual_seed(3)
+    Cn, n = 3, 64000
+    audio = torch.randn(Cn, n, generator=g) * 0.1
+    audio[2] = 0.0                                     # an all-zero padding chunk (std = 0 -> divide by 1e-6)
+    w = torch.randn(512, 1, 10, generator=g) / math.sqrt(10)
+    b = torch.randn(512, generator=g) * 0.3
+    lw = 1 + 0.1 * torch.randn(512, generator=g)
+    lb = 0.1 * torch.randn(512, generator=g)
+    xn = (audio - audio.mean(-1, keepdim=True)) / (audio.std(-1, keepdim=True) + 1e-6)
+    h = F.conv1d(xn[:, None], w, b, stride=5).transpose(1, 2)
+    ref = F.gelu(F.layer_norm(h, (512,), lw, lb, 1e-5))
+    T = ref.shape[1]
+    da, dw, db, dlw, dlb = _dev(audio), _dev(w.view(512, 10)), _dev(b), _dev(lw), _dev(lb)
+    dxn = torch.empty(Cn, n, device="cuda")
+    out = torch.empty(Cn, T, 512, device="cuda")
+    assert L.artalk_op_w2v_front(_p(da), Cn, n, _p(dw), _p(db), _p(dlw), _p(dlb), _p(dxn), _p(out), None) == 0
+    torch.cuda.synchronize()
+    assert (dxn.cpu() - xn).abs().max().item() < 1e-5
+    assert (out.cpu() - ref).abs().max().item() < 5e-5
+
+
+def test_pool_silu():
+    capi, L = _lib()
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(2, 199, 1024, generator=g)
+    xt = X.permute(0, 2, 1)
+    ref = F.silu(torch.cat([F.interpolate(xt, size=(p), mode="area").permute(0, 2, 1) for p in (1, 5, 25, 50, 100)], dim=1))
+    dX = _dev(X)
+    out = torch.empty(2, 181, 1024, device="cuda")
+    assert L.artalk_op_pool_silu(_p(dX), 2, 199, 1024, _p(out), None) == 0
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max().item() < 2e-6
+
+
+def test_bsq_history_matches_oracle():
+    """Multi-scale BSQ + feature recurrences vs the oracle restatement of bitwise_vae.py:227-242,264-288,316-334."""
+    from conftest import get_oracle
+    capi, L = _lib()
+    o = get_oracle("tiny")
+    g = torch.Generator().manual_seed(5)
+    B = 4
+    enc = torch.randn(B, 100, 32, generator=g)
+    bits_ref, margin = o.ms_bsq(enc)
+    fdec_ref = o.vqidx_to_feat(bits_ref, False)
+    ms_ref = o.vqidx_to_feat(bits_ref, True)
+    denc = _dev(enc)
+    bits = torch.zeros(B, 181, 32, dtype=torch.uint8, device="cuda")
+    fdec = torch.empty(B, 100, 32, device="cuda")
+    ms = torch.empty(B, 180, 32, device="cuda")
+    assert L.artalk_op_bsq_history(_p(denc), _p(bits), _p(fdec), _p(ms), B, None) == 0
+    torch.cuda.synchronize()
+    mism = bits.cpu().int() != bits_ref.int()
+    # a sign decision may only differ where the oracle's own margin is at rounding level
+    assert (margin[mism] < 1e-5).all(), (int(mism.sum()), float(margin[mism].max()) if mism.any() else 0)
+    if not mism.any():
+        assert (fdec.cpu() - fdec_ref).abs().max().item() < 1e-6
+        assert (ms.cpu() - ms_ref).abs().max().item() < 1e-6
