@@ -80,7 +80,8 @@ struct artalk_model {
     std::string err;
     bool finalized = false;
     std::map<std::string, Slot> slots;
-    std::vector<void*> allocs;
+    std::vector<void*> allocs;      // weights (model lifetime)
+    std::vector<void*> ws_allocs;   // workspace (re-allocated when a larger batch arrives)
     int64_t weight_bytes = 0;
     // derived sizes
     int n_conv = 0; int conv_T[8]{}; int conv_S[8]{};   // valid frames / padded row stride per conv layer output
@@ -126,14 +127,16 @@ namespace {
 int fail(artalk_model* m, int code, const std::string& msg) { m->err = msg; return code; }
 
 template <typename T>
-T* dalloc(artalk_model* m, int64_t n, bool zero = true) {
+T* dalloc_in(std::vector<void*>& pool, int64_t n) {
     void* p = nullptr;
     if (n <= 0) n = 1;
-    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
-    if (zero) (void)hipMemset(p, 0, n * sizeof(T));
-    m->allocs.push_back(p);
+    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) { pool.push_back(nullptr); return nullptr; }
+    (void)hipMemset(p, 0, n * sizeof(T));
+    pool.push_back(p);
     return reinterpret_cast<T*>(p);
 }
+template <typename T>
+T* dalloc(artalk_model* m, int64_t n) { return dalloc_in<T>(m->allocs, n); }
 
 float* walloc(artalk_model* m, int64_t n) {
     m->weight_bytes += n * 4;
@@ -546,15 +549,21 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
 
 int reserve(artalk_model* m, int maxB, int maxC) {
     const artalk_config& c = m->cfg;
+    if (maxB <= m->ws.maxB && maxC <= m->ws.maxC) return ARTALK_OK;
+    // grow: drop the old workspace (and the graphs that captured its pointers) and allocate the larger one
+    maxB = std::max(maxB, m->ws.maxB); maxC = std::max(maxC, m->ws.maxC);
+    (void)hipDeviceSynchronize();
+    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
+    m->graphs.clear();
+    for (void* p : m->ws_allocs) if (p) (void)hipFree(p);
+    m->ws_allocs.clear();
+    m->ws = Workspace();
     Workspace& w = m->ws;
-    if (maxB <= w.maxB && maxC <= w.maxC) return ARTALK_OK;
-    if (w.maxB > 0) return fail(m, ARTALK_ECAPACITY, "workspace already reserved with a smaller capacity (destroy and re-create)");
     const int CD = c.w2v_conv_dim, Hs = c.w2v_hidden;
     w.maxB = maxB; w.maxC = maxC; w.G = std::min(maxC, 96);
-    const int64_t before = (int64_t)m->allocs.size();
-    auto F = [&](int64_t n) { w.bytes += n * 4; return dalloc<float>(m, n); };
+    auto F = [&](int64_t n) { w.bytes += n * 4; return dalloc_in<float>(m->ws_allocs, n); };
     const int G = w.G;
-    w.src_off = dalloc<long>(m, maxC);
+    w.src_off = dalloc_in<long>(m->ws_allocs, maxC);
     w.xnorm = F((int64_t)G * kSamplesPerChunk);
     w.convA = F(((int64_t)G * m->conv_S[0] + 16) * CD);
     w.convB = F(((int64_t)G * m->conv_S[1] + 16) * CD);
@@ -568,9 +577,9 @@ int reserve(artalk_model* m, int maxB, int maxC) {
     w.x = F((int64_t)maxB * 100 * kE); w.xmod = F((int64_t)maxB * 100 * kE); w.attn_out = F((int64_t)maxB * 100 * kE);
     w.ffn_h = F((int64_t)maxB * 100 * 4 * kE); w.logits = F((int64_t)maxB * 100 * 2 * c.code_dim);
     w.fhat = F((int64_t)maxB * 100 * c.code_dim); w.nextfeat = F((int64_t)maxB * 100 * c.code_dim);
-    w.bits = dalloc<uint8_t>(m, (int64_t)maxB * kNTok * c.code_dim);
-    w.hist_bits = dalloc<uint8_t>(m, (int64_t)maxB * kNTok * c.code_dim);
-    w.has_style = dalloc<uint8_t>(m, maxB);
+    w.bits = dalloc_in<uint8_t>(m->ws_allocs, (int64_t)maxB * kNTok * c.code_dim);
+    w.hist_bits = dalloc_in<uint8_t>(m->ws_allocs, (int64_t)maxB * kNTok * c.code_dim);
+    w.has_style = dalloc_in<uint8_t>(m->ws_allocs, maxB);
     w.prev_fdec = F((int64_t)maxB * 100 * c.code_dim); w.msfeat = F((int64_t)maxB * 180 * c.code_dim);
     const int H = c.vae_hidden;
     w.dec_x = F((int64_t)maxB * 200 * c.code_dim); w.vh = F((int64_t)maxB * 200 * H); w.vln = F((int64_t)maxB * 200 * H);
@@ -580,8 +589,8 @@ int reserve(artalk_model* m, int maxB, int maxC) {
     const int S = c.style_dim, SL = c.style_len;
     w.s_in = F((int64_t)maxB * SL * 128); w.s_h = F((int64_t)maxB * SL * S); w.s_qkv = F((int64_t)maxB * SL * 3 * S);
     w.s_att = F((int64_t)maxB * SL * S); w.s_ffn = F((int64_t)maxB * SL * c.style_ffn); w.s_tmp = F((int64_t)maxB * SL * S);
-    for (size_t i = before; i < m->allocs.size(); ++i)
-        if (!m->allocs[i]) return fail(m, ARTALK_EHIP, "hipMalloc failed while reserving workspace");
+    for (void* p : m->ws_allocs)
+        if (!p) return fail(m, ARTALK_EHIP, "hipMalloc failed while reserving workspace");
     return ARTALK_OK;
 }
 
@@ -634,6 +643,7 @@ void artalk_destroy(artalk_model* m) {
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     for (void* p : m->allocs) if (p) (void)hipFree(p);
+    for (void* p : m->ws_allocs) if (p) (void)hipFree(p);
     delete m;
 }
 
@@ -779,10 +789,7 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
         if (n_chunks[b] <= 0 || (b > 0 && n_chunks[b] > n_chunks[b - 1])) return fail(m, ARTALK_EINVAL, "n_chunks must be positive and non-increasing");
         C += n_chunks[b];
     }
-    if (B > m->ws.maxB || C > m->ws.maxC) {
-        if (m->ws.maxB == 0) { if (int rc = reserve(m, B, (int)C)) return rc; }
-        else return fail(m, ARTALK_ECAPACITY, "batch exceeds the reserved workspace");
-    }
+    if (B > m->ws.maxB || C > m->ws.maxC) { if (int rc = reserve(m, B, (int)C)) return rc; }
     Workspace& w = m->ws;
     // chunk list, chunk-index major: chunk (j, b) for all b with n_chunks[b] > j  -> active clips are a prefix
     std::vector<long> src((size_t)C);
