@@ -103,7 +103,9 @@ struct artalk_model {
     std::vector<StyleLayer> style;
     Workspace ws;
     // profiling
-    bool profiling = false, use_graphs = true;
+    int profiling = 0;        // 0 off, 1 light (graphs stay on; events around eager launches only), 2 full (graphs off)
+    bool use_graphs = true;
+    bool in_graph_body = false;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     std::vector<std::pair<size_t, double>> dom_events;   // (event index of start, flops)
     std::vector<std::pair<int, size_t>> marks;          // (bucket of the interval ending here, event index)
@@ -316,14 +318,14 @@ hipEvent_t next_event(artalk_model* m, hipStream_t s, size_t* idx) {
 // profile buckets (artalk_get_profile): the interval that ENDS at a mark is charged to the mark's bucket
 enum { PB_STYLE = 0, PB_CONV = 1, PB_ENC = 2, PB_ADA = 3, PB_AR = 4, PB_VAE = 5, PB_OTHER = 6 };
 void stage_mark(artalk_model* m, hipStream_t s, int bucket) {
-    if (!m->profiling) return;
+    if (!m->profiling || m->in_graph_body) return;
     size_t i;
     next_event(m, s, &i);
     m->marks.emplace_back(bucket, i);
 }
 
 void gemm(artalk_model* m, const GemmArgs& g, hipStream_t s) {
-    if (m->profiling && gemm_config(g) == 0 && g.M > 0) {
+    if (m->profiling && !m->in_graph_body && gemm_config(g) == 0 && g.M > 0) {
         size_t i0, i1;
         next_event(m, s, &i0);
         launch_gemm(g, s);
@@ -773,7 +775,7 @@ int artalk_reserve(artalk_model* m, int max_batch, int max_total_chunks) {
 int64_t artalk_workspace_bytes(const artalk_model* m) { return m ? m->ws.bytes : 0; }
 int64_t artalk_weight_bytes(const artalk_model* m) { return m ? m->weight_bytes : 0; }
 
-int artalk_set_profiling(artalk_model* m, int enable) { if (!m) return ARTALK_EINVAL; m->profiling = enable != 0; return ARTALK_OK; }
+int artalk_set_profiling(artalk_model* m, int level) { if (!m || level < 0 || level > 2) return ARTALK_EINVAL; m->profiling = level; return ARTALK_OK; }
 int artalk_set_graphs(artalk_model* m, int enable) { if (!m) return ARTALK_EINVAL; m->use_graphs = enable != 0; return ARTALK_OK; }
 
 int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_stride, const int64_t* n_chunks, int B,
@@ -820,7 +822,7 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
         HIPCHK(m, hipMemcpy2DAsync(out_hist_bits_dev, (size_t)(maxch + 1) * bits_row, w.hist_bits, bits_row, bits_row, B,
                                    hipMemcpyDeviceToDevice, s));
     stage_mark(m, s, PB_VAE);
-    const bool graphs = m->use_graphs && !m->profiling;
+    const bool graphs = m->use_graphs && m->profiling != 2;
     for (int64_t j = 0; j < maxch; ++j) {
         const int Bn = Bj[j];
         // AdaLN table of this chunk index for all blocks + head: SiLU(cond) @ [W_0;...;W_11;W_head]^T
@@ -833,13 +835,16 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
                 hipGraph_t graph = nullptr;
                 hipGraphExec_t exec = nullptr;
                 HIPCHK(m, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                m->in_graph_body = true;
                 run_chunk_body(m, Bn, s);
+                m->in_graph_body = false;
                 HIPCHK(m, hipStreamEndCapture(s, &graph));
                 HIPCHK(m, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
                 (void)hipGraphDestroy(graph);
                 it = m->graphs.emplace(Bn, exec).first;
             }
             HIPCHK(m, hipGraphLaunch(it->second, s));
+            stage_mark(m, s, PB_AR);   // light profiling: the whole captured body (AR steps + VAE) is charged to the AR bucket
         } else {
             run_chunk_body(m, Bn, s);
         }

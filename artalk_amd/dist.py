@@ -1,0 +1,68 @@
+"""Data-parallel sharding of independent clips over the GPUs of one node.
+
+Clips share nothing but read-only weights and chunks inside a clip are sequential, so the path shards by clip:
+one process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm), weights replicated
+(2 GB of 288 GB), no data-path collective.  The only exchange is the optional collection of results: one
+all-gather of the padded FLAME codes and one of the lengths.  The same code runs on the gloo backend with
+CPU tensors (tests/test_dist_gloo.py).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world_size: int) -> range:
+    """Contiguous block partition: rank r gets items [r*n/W, (r+1)*n/W) (sizes differ by at most one)."""
+    lo = (n_items * rank) // world_size
+    hi = (n_items * (rank + 1)) // world_size
+    return range(lo, hi)
+
+
+def gather_clips(local: Sequence[torch.Tensor], max_frames: int, group=None) -> List[torch.Tensor]:
+    """All-gather per-clip results ``(T_i, D)`` of every rank; returns the clips of all ranks in rank order on
+    every rank.  Every rank must pass the same number of clips (pad the shard with empty ``(0, D)`` tensors)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return list(local)
+    n = len(local)
+    D = local[0].shape[1]
+    dev = local[0].device
+    buf = torch.zeros(n, max_frames, D, dtype=local[0].dtype, device=dev)
+    lens = torch.zeros(n, dtype=torch.int64, device=dev)
+    for i, t in enumerate(local):
+        buf[i, : t.shape[0]] = t
+        lens[i] = t.shape[0]
+    all_buf = torch.empty(world * n, max_frames, D, dtype=buf.dtype, device=dev)
+    all_len = torch.empty(world * n, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_buf, buf, group=group)
+    dist.all_gather_into_tensor(all_len, lens, group=group)
+    all_len = all_len.cpu().tolist()
+    return [all_buf[i, : all_len[i]] for i in range(world * n)]
+
+
+def run_sharded(infer_fn, audios: Sequence[torch.Tensor], styles=None, gather: bool = True, group=None):
+    """Shard ``audios`` over the ranks, run ``infer_fn(list_of_audio, list_of_style)`` on the local shard and
+    (optionally) all-gather.  Result order equals input order; shards are padded to equal size with empties."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = len(audios)
+    mine = shard_range(n, rank, world)
+    loc_a = [audios[i] for i in mine]
+    loc_s = [styles[i] for i in mine] if styles is not None else None
+    out = infer_fn(loc_a, loc_s) if loc_a else []
+    if not gather or world == 1:
+        return out
+    per = max(len(shard_range(n, r, world)) for r in range(world))
+    D = out[0].shape[1] if out else 106
+    dev = out[0].device if out else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+    padded = list(out) + [torch.zeros(0, D, device=dev)] * (per - len(out))
+    max_frames = max(-(-int(a.shape[0]) * 25 // 16000) for a in audios)   # ceil(N/640)
+    allc = gather_clips(padded, max_frames, group)
+    res = []
+    for r in range(world):
+        k = len(shard_range(n, r, world))
+        res.extend(allc[r * per: r * per + k])
+    return res

@@ -143,8 +143,9 @@ class BitwiseARModel:
     def weight_bytes(self):
         return int(capi.lib().artalk_weight_bytes(self._h))
 
-    def set_profiling(self, on: bool):
-        capi.lib().artalk_set_profiling(self._h, int(bool(on)))
+    def set_profiling(self, level: int):
+        """0 off, 1 light (graphs on, eager launches bracketed), 2 full (graphs off)."""
+        capi.lib().artalk_set_profiling(self._h, int(level))
 
     def set_graphs(self, on: bool):
         capi.lib().artalk_set_graphs(self._h, int(bool(on)))

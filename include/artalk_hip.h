@@ -88,12 +88,15 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
 /* Savitzky-Golay smoothing of inference.py:89-95 on the device: in/out [T][106] f32, T >= 9. */
 int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, void* stream);
 
-/* Per-call stage timing (HIP events on the call's stream).  enable=1 makes artalk_infer record events;
- * artalk_get_profile synchronises them and returns milliseconds / counters of the LAST artalk_infer:
+/* Per-call stage timing (HIP events on the call's stream).  level 0 = off; 1 = light: hipGraphs stay on, events
+ * bracket the eager launches only (wav2vec2, AdaLN table, graph replays) - cheap enough for a timed region;
+ * 2 = full: graphs off, events also inside the AR/VAE body.  artalk_get_profile synchronises and returns the
+ * LAST artalk_infer's numbers (milliseconds / counters):
  *   out[0] style  out[1] wav2vec2 conv stack  out[2] wav2vec2 encoder  out[3] AdaLN table GEMM
- *   out[4] AR scale steps  out[5] VAE decode+re-encode  out[6] total
- *   out[7] launches of the dominant kernel (128x128 fp32 MFMA GEMM)  out[8] their summed ms  out[9] their summed FLOP */
-int artalk_set_profiling(artalk_model* m, int enable);
+ *   out[4] AR scale steps (level 1: whole captured body)  out[5] VAE decode+re-encode (level 2 only; + initial history)
+ *   out[6] total  out[7] bracketed launches of the dominant kernel (128x128 fp32 MFMA GEMM)  out[8] their summed ms
+ *   out[9] their summed FLOP */
+int artalk_set_profiling(artalk_model* m, int level);
 int artalk_get_profile(artalk_model* m, double* out, int n);
 /* Replay the AR/VAE part from hipGraphs captured per active-batch size (default 1 = on). */
 int artalk_set_graphs(artalk_model* m, int enable);
