@@ -133,7 +133,7 @@ def manifest(cfg: ARTalkConfig):
 
 
 def n_params(cfg: ARTalkConfig):
-    return sum(int(np.prod(s)) for s, _, init in manifest(cfg).values() if not init[0].startswith("buf"))
+    return sum(int(np.prod(s)) for s, _, init in manifest(cfg).values() if not init[0].startswith(("buf", "stat")))
 
 
 # --------------------------------------------------------------------------------------

@@ -1,0 +1,75 @@
+"""Data-parallel clip sharding + result collection (artalk_amd/dist.py) with world_size 2 on the gloo backend.
+The GPU path uses the same functions with backend 'nccl' (RCCL); here infer_fn is a stand-in that makes the
+result a pure function of the clip so the gathered order can be checked."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from artalk_amd.dist import gather_clips, run_sharded, shard_range
+
+
+def _fake_infer(audios, styles):
+    outs = []
+    for a in audios:
+        T = -(-a.shape[0] * 25 // 16000)
+        outs.append(a[:1].repeat(T, 106) + torch.arange(T, dtype=torch.float32)[:, None])
+    return outs
+
+
+def _worker(rank, world, port, n_clips, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    audios = [torch.full((16000 + 640 * i,), float(i + 1)) for i in range(n_clips)]
+    res = run_sharded(_fake_infer, audios, None, gather=True)
+    want = _fake_infer(audios, None)
+    ok = len(res) == n_clips and all(torch.equal(r, w) for r, w in zip(res, want))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(n_clips):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_shard_range_partitions():
+    for n in (1, 5, 32, 33, 256):
+        for w in (1, 2, 4, 8):
+            idx = [i for r in range(w) for i in shard_range(n, r, w)]
+            assert idx == list(range(n))
+            sizes = [len(shard_range(n, r, w)) for r in range(w)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_gather_world2_even():
+    _run(6)
+
+
+def test_gather_world2_ragged():
+    _run(5)     # shards of 2 and 3 clips with different lengths
+
+
+def test_gather_single_process_is_identity():
+    clips = [torch.ones(3, 106), torch.zeros(5, 106)]
+    out = gather_clips(clips, 5)
+    assert all(torch.equal(a, b) for a, b in zip(out, clips))

@@ -1,0 +1,91 @@
+"""The CPU oracle against the vectors produced by the reference itself (oracle/make_golden.py): this is what pins
+the oracle.  Bits must be identical and FLAME codes equal to 1e-5 (they are bit-identical in the build container;
+the tolerance only allows for a different BLAS on another host)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import get_oracle, get_state_dict, golden_inputs, load_golden
+
+TINY = ["tiny_4s_s0", "tiny_10s_s1_style", "tiny_6p3s_s2"]
+
+
+def _run(case):
+    g = load_golden(case)
+    name = case.split("_")[0]
+    o = get_oracle(name)
+    cfg, sd = get_state_dict(name)
+    audio, style = golden_inputs(g, sd)
+    rec = {}
+    out = o.inference({"audio": audio[None], "style_motion": style[None] if style is not None else None}, record=rec)[0].numpy()
+    return g, out, rec
+
+
+@pytest.mark.parametrize("case", TINY)
+def test_oracle_matches_reference_tiny(case):
+    g, out, rec = _run(case)
+    assert out.shape == g["out"].shape
+    bits = np.packbits(torch.cat(rec["bits"]).numpy().astype(np.uint8), axis=-1)
+    hist = np.packbits(torch.cat(rec["hist_bits"]).numpy().astype(np.uint8), axis=-1)
+    assert (bits == g["bits"]).all()
+    assert (hist == g["hist_bits"]).all()
+    assert np.abs(out - g["out"]).max() < 1e-5
+    w2v = torch.cat(rec["w2v"]).numpy()
+    assert np.abs(w2v[:, :, :16] - g["w2v_slice"]).max() < 1e-5
+    # the margins recorded by the oracle are the reference's margins
+    lm = torch.stack([m[0] for m in rec["logit_margin"]]).numpy()
+    assert np.abs(lm - g["logit_margin"].astype(np.float32)).max() < 2e-2
+
+
+def test_oracle_matches_reference_full_config():
+    """One full-depth case (12 AR blocks, 24 wav2vec2 layers, 8+8 VAE blocks; ~0.5 G parameters)."""
+    g, out, rec = _run("full_4s_s2")
+    bits = np.packbits(torch.cat(rec["bits"]).numpy().astype(np.uint8), axis=-1)
+    assert (bits == g["bits"]).all()
+    assert np.abs(out - g["out"]).max() < 1e-5
+
+
+def test_engine_postprocessing_matches_reference():
+    """inference.py:52-56,89-95: savgol (5,2) / (9,3) on dims 100:103, [:clip_length], dims 104: zeroed."""
+    from artalk_oracle import engine_inference
+    g = load_golden("tiny_10s_s1_style")
+    o = get_oracle("tiny")
+    cfg, sd = get_state_dict("tiny")
+    audio, style = golden_inputs(g, sd)
+    eng = engine_inference(o, audio, style[None], clip_length=750).numpy()
+    assert np.abs(eng - g["engine_out"]).max() < 1e-5
+    assert np.abs(eng[:, 104:]).max() == 0.0
+    short = engine_inference(o, audio, style[None], clip_length=50)
+    assert short.shape == (50, 106)
+
+
+def test_kv_cache_is_legal():
+    """bits of levels < p recomputed at step p equal the bits first produced (the property the
+    HIP path's KV cache relies on), checked on the oracle by comparing each step's argmax over its prefix."""
+    import math
+    import torch.nn.functional as F
+    o = get_oracle("tiny")
+    cfg, sd = get_state_dict("tiny")
+    from artalk_amd.synth import synth_audio
+    audio = torch.from_numpy(synth_audio(5, 4.0))[None]
+    w, pn = o.w, o.patch_nums
+    style_cond = w["null_style_cond"]
+    lvl = w["lvl_embed.weight"][w["lvl_idx"]]
+    lvl_pos, prev_lvl_pos = lvl + w["pos_embed"], lvl + w["prev_pos_embed"]
+    prev_bits, _ = o.quant_to_vqidx(torch.zeros(1, 100, 106))
+    prev_feat = torch.cat([style_cond, F.linear(o.vqidx_to_feat(prev_bits, True), w["vqfeat_embed.weight"], w["vqfeat_embed.bias"])], 1)
+    feat_a = o.wav2vec(audio).permute(0, 2, 1)
+    cond_all = torch.cat([F.interpolate(feat_a, size=(p), mode="area").permute(0, 2, 1) for p in pn], dim=1)
+    nxt, seen = style_cond, None
+    for pidx in range(5):
+        L = sum(pn[:pidx + 1])
+        x = nxt + lvl_pos[:, :L]
+        bias = w["attn_bias_for_masking"][:, :, :L, :L + 181]
+        for i in range(cfg.ar_depth):
+            x = o.ar_block(i, x, prev_feat + prev_lvl_pos, cond_all[:, :L], bias)
+        bits = o.ar_head(x, cond_all[:, :L]).view(1, L, -1, 2).argmax(-1)
+        if seen is not None:
+            assert torch.equal(bits[:, :seen.shape[1]], seen)
+        seen = bits
+        if pidx < 4:
+            nxt = torch.cat([style_cond, F.linear(o.vqidx_to_ar_vqfeat(pidx, bits), w["vqfeat_embed.weight"], w["vqfeat_embed.bias"])], 1)
