@@ -105,7 +105,8 @@ struct artalk_model {
     // profiling
     int profiling = 0;        // 0 off, 1 light (graphs stay on; events around eager launches only), 2 full (graphs off)
     bool use_graphs = true;
-    bool in_graph_body = false;
+    bool in_graph_body = false;   // capturing: no events
+    bool in_body = false;         // inside run_chunk_body (captured or eager)
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     std::vector<std::pair<size_t, double>> dom_events;   // (event index of start, flops)
     std::vector<std::pair<int, size_t>> marks;          // (bucket of the interval ending here, event index)
@@ -324,8 +325,10 @@ void stage_mark(artalk_model* m, hipStream_t s, int bucket) {
     m->marks.emplace_back(bucket, i);
 }
 
-void gemm(artalk_model* m, const GemmArgs& g, hipStream_t s) {
-    if (m->profiling && !m->in_graph_body && gemm_config(g) == 0 && g.M > 0) {
+void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
+    GemmArgs g = g0;
+    g.graph_tag = m->in_body ? 1 : 0;
+    if (m->profiling && !m->in_body && gemm_config(g) == 0 && g.M > 0) {
         size_t i0, i1;
         next_event(m, s, &i0);
         launch_gemm(g, s);
@@ -475,6 +478,7 @@ void run_reencode(artalk_model* m, int B, hipStream_t s) {
 
 // Everything of one chunk index that depends only on (B, fixed workspace pointers): capturable as one hipGraph.
 void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
+    struct BodyScope { artalk_model* m; BodyScope(artalk_model* x) : m(x) { m->in_body = true; } ~BodyScope() { m->in_body = false; } } scope(m);
     const artalk_config& c = m->cfg;
     Workspace& w = m->ws;
     const long ldada = m->ada_n;

@@ -18,7 +18,10 @@ namespace artalk {
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;   // floats; 144-B rows
 
-template <int BM, int BN, int WM, int WN, int AMODE>
+// TAG only separates instantiations: launches captured into the AR/VAE hipGraph use TAG=1 so that the eager launches
+// (TAG=0: wav2vec2 stack + AdaLN table, the dominant kernel of the path) form one kernel symbol whose every launch is
+// bracketed by HIP events in bench.py and listed as one row by rocprofv3.
+template <int BM, int BN, int WM, int WN, int AMODE, int TAG = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_LD = BM * BK / 4 / 256, B_LD = BN * BK / 4 / 256;
@@ -149,7 +152,9 @@ static void launch_cfg(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     const size_t lds = 2 * (BM + BN) * LDS_LD * sizeof(float);
     dim3 grid(tiles, 1, g.batch);
-    if (g.amode == 0)
+    if (g.amode == 0 && g.graph_tag && BM == 128 && BN == 128)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, 0, 1>), grid, dim3(256), lds, s, g);
+    else if (g.amode == 0)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, 0>), grid, dim3(256), lds, s, g);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), lds, s, g);
