@@ -328,7 +328,7 @@ void stage_mark(artalk_model* m, hipStream_t s, int bucket) {
 void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
     GemmArgs g = g0;
     g.graph_tag = m->in_body ? 1 : 0;
-    if (m->profiling && !m->in_body && gemm_config(g) == 0 && g.M > 0) {
+    if (m->profiling && !m->in_body && gemm_config(g) == 2 && g.M > 0) {
         size_t i0, i1;
         next_event(m, s, &i0);
         launch_gemm(g, s);
@@ -899,6 +899,16 @@ int artalk_op_gemm(const float* A, int64_t lda, const float* W, const float* bia
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = bias; g.C = C; g.ldc = N; g.gate = gate; g.ldg = N; g.R = R; g.ldr = N;
     g.M = M; g.N = N; g.K = K; g.act = act;
+    launch_gemm(g, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+}
+
+int artalk_op_gemm_ex(const float* A, int64_t lda, const float* W, const float* bias, float* C, int M, int N, int K, int act,
+                      int force_cfg, void* stream) {
+    if (!A || !W || !C || K % 32 != 0 || M < 0 || N <= 0) return ARTALK_EINVAL;
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = bias; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
+    g.force_cfg = force_cfg;
     launch_gemm(g, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }

@@ -18,8 +18,8 @@ namespace artalk {
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;   // floats; 144-B rows
 
-// TAG only separates instantiations: launches captured into the AR/VAE hipGraph use TAG=1 so that the eager launches
-// (TAG=0: wav2vec2 stack + AdaLN table, the dominant kernel of the path) form one kernel symbol whose every launch is
+// TAG only separates instantiations: 64x64 launches captured into the AR/VAE hipGraph use TAG=1 so that the eager 64x64
+// launches (TAG=0: wav2vec2 encoder + AdaLN table, the dominant kernel of the path) form one kernel symbol whose every launch is
 // bracketed by HIP events in bench.py and listed as one row by rocprofv3.
 template <int BM, int BN, int WM, int WN, int AMODE, int TAG = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
@@ -152,7 +152,7 @@ static void launch_cfg(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     const size_t lds = 2 * (BM + BN) * LDS_LD * sizeof(float);
     dim3 grid(tiles, 1, g.batch);
-    if (g.amode == 0 && g.graph_tag && BM == 128 && BN == 128)
+    if (g.amode == 0 && g.graph_tag && BM == 64 && BN == 64)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, 0, 1>), grid, dim3(256), lds, s, g);
     else if (g.amode == 0)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, 0>), grid, dim3(256), lds, s, g);
@@ -160,12 +160,16 @@ static void launch_cfg(const GemmArgs& g, hipStream_t s) {
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), lds, s, g);
 }
 
-// 0: 128x128 (the dominant kernel of the path), 1: 128x64, 2: 64x64, 3: 32x128
+// Tile choice, from tools/gemm_bench.py on MI355X (profiles/gemm_bench_r01.log):
+//   0: 128x128  best only for the long, narrow conv-as-GEMM shapes (M >= 150k, N = 512): 116 vs 113 TF/s
+//   1: 128x64   grouped positional conv (N = 64 per group)
+//   2: 64x64    everything else: 4 workgroups/CU hide the staging latency better than 2 (110-114 TF/s on the
+//               wav2vec2 encoder shapes vs 89-106 for 128x128) and it quantises better on mid-size grids
+//   3: 32x128   M <= 32 (first scale step at small batch)
 int gemm_config(const GemmArgs& g) {
-    const long tm128 = (g.M + 127) / 128;
-    if (g.N <= 64 && tm128 * g.batch >= 256) return 1;
-    const long t128 = tm128 * ((g.N + 127) / 128) * g.batch;
-    if (t128 >= 384) return 0;
+    if (g.force_cfg >= 0) return g.force_cfg;
+    if (g.amode == 1) return 1;
+    if (g.M >= 150000 && g.N <= 512) return 0;
     if (g.M > 32) return 2;
     return 3;
 }

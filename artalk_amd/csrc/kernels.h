@@ -38,10 +38,11 @@ struct GemmArgs {
     // amode 1: grouped positional conv window (wav2vec2 pos_conv_embed): row m = (c, t) with
     // t = m % pc_tstride, k = (tap, ci): A[m,k] = X[c*pc_tstride + t + tap - pc_pad, ci] if in [0,pc_T) else 0
     int amode = 0; int pc_T = 0, pc_tstride = 0, pc_pad = 0, pc_cin = 0;
+    int force_cfg = -1;  // >= 0: tile configuration override (tuning/tests)
     int graph_tag = 0;   // 1 for launches inside the captured AR/VAE body (separate kernel symbol, same code)
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);
-int gemm_config(const GemmArgs& g);   // 0: 128x128 tile (dominant kernel), 1: 128x64, 2: 64x64, 3: 32x128
+int gemm_config(const GemmArgs& g);   // 0: 128x128, 1: 128x64, 2: 64x64 (dominant kernel), 3: 32x128
 // Average kernel time helper for benches: FLOPs of one launch
 static inline double gemm_flops(const GemmArgs& g) { return 2.0 * g.M * (double)g.N * g.K * g.batch; }
 

@@ -6,7 +6,7 @@ re-encode) over one batch of 32 synthetic 10-second 16 kHz clips that are alread
 launched by ``python -m torch.distributed.run`` (one rank per GPU): every rank takes its own 32 clips (weak scaling,
 clips are independent) and the step ends with the RCCL all-gather that collects the FLAME codes of all ranks.
 
-Prints ONE JSON line (rank 0).  Besides the contract keys it carries ``roofline`` (the dominant kernel: the 128x128
+Prints ONE JSON line (rank 0).  Besides the contract keys it carries ``roofline`` (the dominant kernel: the 64x64-tile
 fp32 MFMA GEMM, timed with HIP events around every eager launch of it inside the timed region) and ``cpu_baseline``
 (the CPU oracle, a restatement pinned bit-exact to the reference, timed on the host cores for a bounded sample).
 """
@@ -149,7 +149,7 @@ def main():
     roofline = {
         "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(dom_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-        "kernel": "gemm_f32_kernel<128,128,2,2> (v_mfma_f32_32x32x2_f32)",
+        "kernel": "gemm_f32_kernel<64,64,2,2,0,0> (v_mfma_f32_32x32x2_f32), eager launches: wav2vec2 + AdaLN table",
         "launches": int(prof["dom_launches"]), "avg_launch_ms": round(prof["dom_ms"] / max(prof["dom_launches"], 1), 4),
         "share_of_step_ms": round(prof["dom_ms"], 2),
     }
