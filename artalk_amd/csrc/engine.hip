@@ -328,7 +328,7 @@ void stage_mark(artalk_model* m, hipStream_t s, int bucket) {
 void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
     GemmArgs g = g0;
     g.graph_tag = m->in_body ? 1 : 0;
-    if (m->profiling && !m->in_body && gemm_config(g) == 2 && g.M > 0) {
+    if (m->profiling && !m->in_body && gemm_config(g) == 4 && g.M > 0) {
         size_t i0, i1;
         next_event(m, s, &i0);
         launch_gemm(g, s);
@@ -910,6 +910,13 @@ int artalk_op_gemm_ex(const float* A, int64_t lda, const float* W, const float* 
     g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = bias; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
     g.force_cfg = force_cfg;
     launch_gemm(g, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+}
+
+// out_dev: blocks*256 floats of scratch; *flops receives the FLOPs of the launch (time it with events on `stream`)
+int artalk_op_mfma_f32_peak(float* out_dev, int blocks, int iters, int nacc, double* flops, void* stream) {
+    if (!out_dev || !flops || blocks <= 0 || iters <= 0) return ARTALK_EINVAL;
+    *flops = launch_mfma_f32_peak(out_dev, blocks, iters, nacc, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }
 

@@ -15,37 +15,54 @@
 
 namespace artalk {
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;   // floats; 144-B rows
 
 // TAG only separates instantiations: 64x64 launches captured into the AR/VAE hipGraph use TAG=1 so that the eager 64x64
 // launches (TAG=0: wav2vec2 encoder + AdaLN table, the dominant kernel of the path) form one kernel symbol whose every launch is
 // bracketed by HIP events in bench.py and listed as one row by rocprofv3.
-template <int BM, int BN, int WM, int WN, int AMODE, int TAG = 0>
+template <int BM, int BN, int WM, int WN, int BK, int AMODE, int TAG = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+    constexpr int LDS_LD = BK + 4;                 // floats; the +4 pad keeps the ds_read_b128 fragment reads conflict-free
+    constexpr int TPR = BK / 4, RPP = 256 / TPR;   // staging: threads per row, rows per pass
+    constexpr int NQ = BK / 8;                     // 16-byte chunks of a fragment per lane (lane half h holds k in [h*BK/2, (h+1)*BK/2))
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_LD = BM * BK / 4 / 256, B_LD = BN * BK / 4 / 256;
+    constexpr int A_LD = BM / RPP, B_LD = BN / RPP;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1, "tile config");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                     // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;   // [2][BN][LDS_LD]
 
     const int tid = threadIdx.x;
-    const int tiles_n = (g.N + BN - 1) / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so first give each
+    // XCD a contiguous run of the tile sequence (bijective remap), then walk the sequence in groups of GM row-tiles,
+    // column-major inside a group: the GM A-panels (GM*BM*K floats) stay L2-resident while the W panels stream past once
+    // per group instead of once per row-tile.  Placement only affects speed, never results.
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    int tm, tn;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GM = (BM >= 128) ? 4 : 8;
+        const int width = GM * tiles_n;
+        const int group = idx / width, first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        const int in_g = idx - group * width;
+        tn = in_g / gsz;
+        tm = first_m + (in_g - tn * gsz);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
     const float* __restrict__ A = g.A + z * g.sA;
     const float* __restrict__ W = g.W + z * g.sW;
 
     f32x4 ra[A_LD], rb[B_LD];
-    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;   // 8 threads cover one 32-float row segment
+    const int lrow = tid / TPR, lc4 = (tid % TPR) * 4;   // TPR threads cover one BK-float row segment
 
     auto gload = [&](int kt) {
         const int k = kt * BK + lc4;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            const int gm = m0 + lrow + i * 32;
+            const int gm = m0 + lrow + i * RPP;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (gm < g.M) {
                 if (AMODE == 0) {
@@ -62,7 +79,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
-            const int gn = n0 + lrow + i * 32;
+            const int gn = n0 + lrow + i * RPP;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (gn < g.N) v = *reinterpret_cast<const f32x4*>(W + (long)gn * g.ldw + k);
             rb[i] = v;
@@ -71,10 +88,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i)
-            *reinterpret_cast<f32x4*>(As + (buf * BM + lrow + i * 32) * LDS_LD + lc4) = ra[i];
+            *reinterpret_cast<f32x4*>(As + (buf * BM + lrow + i * RPP) * LDS_LD + lc4) = ra[i];
 #pragma unroll
         for (int i = 0; i < B_LD; ++i)
-            *reinterpret_cast<f32x4*>(Bs + (buf * BN + lrow + i * 32) * LDS_LD + lc4) = rb[i];
+            *reinterpret_cast<f32x4*>(Bs + (buf * BN + lrow + i * RPP) * LDS_LD + lc4) = rb[i];
     };
 
     const int wave = tid >> 6, lane = tid & 63;
@@ -89,26 +106,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = g.K / BK;
+    const int nk = g.K / BK;   // K % 32 == 0 is required by the callers, so this holds for BK = 16 and 32
     gload(0);
     lstore(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
-        const float* as = As + (buf * BM + wm * (BM / WM) + r) * LDS_LD + h * 16;
-        const float* bs = Bs + (buf * BN + wn * (BN / WN) + r) * LDS_LD + h * 16;
-        f32x4 a[TM][4], b[TN][4];
+        const float* as = As + (buf * BM + wm * (BM / WM) + r) * LDS_LD + h * (BK / 2);
+        const float* bs = Bs + (buf * BN + wn * (BN / WN) + r) * LDS_LD + h * (BK / 2);
+        f32x4 a[TM][NQ], b[TN][NQ];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[i][q] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_LD + q * 4);
+            for (int q = 0; q < NQ; ++q) a[i][q] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_LD + q * 4);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b[j][q] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDS_LD + q * 4);
+            for (int q = 0; q < NQ; ++q) b[j][q] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDS_LD + q * 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -147,29 +164,32 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = 32>
 static void launch_cfg(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    const size_t lds = 2 * (BM + BN) * LDS_LD * sizeof(float);
+    const size_t lds = 2 * (BM + BN) * (BK + 4) * sizeof(float);
     dim3 grid(tiles, 1, g.batch);
     if (g.amode == 0 && g.graph_tag && BM == 64 && BN == 64)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, 0, 1>), grid, dim3(256), lds, s, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, 0, 1>), grid, dim3(256), lds, s, g);
     else if (g.amode == 0)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, 0>), grid, dim3(256), lds, s, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, 0>), grid, dim3(256), lds, s, g);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), lds, s, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, 1>), grid, dim3(256), lds, s, g);
 }
 
-// Tile choice, from tools/gemm_bench.py on MI355X (profiles/gemm_bench_r01.log):
-//   0: 128x128  best only for the long, narrow conv-as-GEMM shapes (M >= 150k, N = 512): 116 vs 113 TF/s
-//   1: 128x64   grouped positional conv (N = 64 per group)
-//   2: 64x64    everything else: 4 workgroups/CU hide the staging latency better than 2 (110-114 TF/s on the
-//               wav2vec2 encoder shapes vs 89-106 for 128x128) and it quantises better on mid-size grids
-//   3: 32x128   M <= 32 (first scale step at small batch)
+// Tile choice, from tools/gemm_bench.py on MI355X (profiles/r01_gemm_bench.log).  A register-only MFMA loop sustains
+// 148 TF/s with 4 independent accumulators per wave and 130 TF/s with one dependent chain (profiles/r01_mfma_peak.log),
+// so the big shapes want 128x128 (4 accumulators) and enough workgroups per CU to hide staging (BK=16: 3 per CU).
+//   4: 128x128, BK=16   grids of >= 1024 tiles: wav2vec2 encoder, conv-as-GEMM, AdaLN table (the dominant kernel)   113-125 TF/s
+//   2: 64x64,   BK=32   smaller grids with M > 32 (AR / VAE steps; 4 workgroups/CU)                                  50-100 TF/s
+//   1: 128x64,  BK=32   grouped positional conv (N = 64 per group)
+//   3: 32x128,  BK=32   M <= 32 (first scale step at small batch)
+//   0,5,6,7: kept for tuning (128x128 BK=32; 128x64, 64x128, 64x64 with BK=16)
 int gemm_config(const GemmArgs& g) {
     if (g.force_cfg >= 0) return g.force_cfg;
     if (g.amode == 1) return 1;
-    if (g.M >= 150000 && g.N <= 512) return 0;
+    const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    if (t128 >= 1024) return 4;
     if (g.M > 32) return 2;
     return 3;
 }
@@ -180,8 +200,49 @@ void launch_gemm(const GemmArgs& g, hipStream_t s) {
         case 0: launch_cfg<128, 128, 2, 2>(g, s); break;
         case 1: launch_cfg<128, 64, 2, 2>(g, s); break;
         case 2: launch_cfg<64, 64, 2, 2>(g, s); break;
+        case 3: launch_cfg<32, 128, 1, 4>(g, s); break;
+        // experimental BK=16 variants (more workgroups per CU)
+        case 4: launch_cfg<128, 128, 2, 2, 16>(g, s); break;
+        case 5: launch_cfg<128, 64, 2, 2, 16>(g, s); break;
+        case 6: launch_cfg<64, 128, 2, 2, 16>(g, s); break;
+        case 7: launch_cfg<64, 64, 2, 2, 16>(g, s); break;
         default: launch_cfg<32, 128, 1, 4>(g, s); break;
     }
 }
 
+}  // namespace artalk
+
+// ---- calibration: register-only v_mfma_f32_32x32x2_f32 loop (no memory traffic) on non-trivial data.  Gives the
+// fp32-MFMA rate the chip sustains at the clock it holds under this load: the ceiling the GEMM is compared with.
+namespace artalk {
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_f32_peak_kernel(float* out, int iters, float seed) {
+    f32x16 acc[NACC];
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float a = seed * (float)(lane + 1) * 1.0009765625f, b = 0.5f + seed * (float)(63 - lane);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 32 / NACC; ++u) {
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            a = -a * 0.999f; b = b * 1.0001f;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// returns FLOPs issued by one launch; nacc = independent accumulators per wave (1 = one dependent chain, like the 64x64 GEMM)
+double launch_mfma_f32_peak(float* out, int blocks, int iters, int nacc, hipStream_t s) {
+    if (nacc == 1) hipLaunchKernelGGL(mfma_f32_peak_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
+    else hipLaunchKernelGGL(mfma_f32_peak_kernel<4>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
+    return (double)blocks * 4 /*waves*/ * iters * 32.0 /*mfma per iter*/ * (32.0 * 32 * 2 * 2);
+}
 }  // namespace artalk

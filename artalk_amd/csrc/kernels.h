@@ -42,7 +42,7 @@ struct GemmArgs {
     int graph_tag = 0;   // 1 for launches inside the captured AR/VAE body (separate kernel symbol, same code)
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);
-int gemm_config(const GemmArgs& g);   // 0: 128x128, 1: 128x64, 2: 64x64 (dominant kernel), 3: 32x128
+int gemm_config(const GemmArgs& g);   // 4: 128x128 BK16 (dominant kernel), 2: 64x64, 1: 128x64, 3: 32x128; 0,5,6,7 tuning variants
 // Average kernel time helper for benches: FLOPs of one launch
 static inline double gemm_flops(const GemmArgs& g) { return 2.0 * g.M * (double)g.N * g.K * g.batch; }
 
@@ -109,6 +109,7 @@ void launch_add_row(float* X, const float* v, int M, int D, hipStream_t s);
 // Savitzky-Golay post filter of reference inference.py:89-95 on device: in [T,106] -> out [T,106]
 void launch_savgol(const float* in, float* out, int T, int D, hipStream_t s);
 
+double launch_mfma_f32_peak(float* out, int blocks, int iters, int nacc, hipStream_t s);   // calibration kernel, returns FLOPs
 void init_ms_tables();   // uploads the (tiny) interpolation tables to __constant__ memory; idempotent
 
 }  // namespace artalk

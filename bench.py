@@ -6,7 +6,7 @@ re-encode) over one batch of 32 synthetic 10-second 16 kHz clips that are alread
 launched by ``python -m torch.distributed.run`` (one rank per GPU): every rank takes its own 32 clips (weak scaling,
 clips are independent) and the step ends with the RCCL all-gather that collects the FLAME codes of all ranks.
 
-Prints ONE JSON line (rank 0).  Besides the contract keys it carries ``roofline`` (the dominant kernel: the 64x64-tile
+Prints ONE JSON line (rank 0).  Besides the contract keys it carries ``roofline`` (the dominant kernel: the 128x128-tile
 fp32 MFMA GEMM, timed with HIP events around every eager launch of it inside the timed region) and ``cpu_baseline``
 (the CPU oracle, a restatement pinned bit-exact to the reference, timed on the host cores for a bounded sample).
 """
@@ -146,10 +146,19 @@ def main():
         parity = {"case": "full_10s_s0", "flame_max_abs_err": float(np.abs(outs[0].cpu().numpy() - g["out"]).max())}
 
     dom_tflops = prof["dom_flop"] / (prof["dom_ms"] * 1e-3) / 1e12 if prof["dom_ms"] > 0 else 0.0
+    # HBM traffic per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of
+    # this same command, separate runs; profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes)
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath):
+        for k, v in json.load(open(tpath)).items():
+            if k.startswith("gemm_f32_kernel<128, 128, 2, 2, 16, 0, 0>"):
+                traffic = round(v["hbm_bytes_per_launch"])
     roofline = {
         "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(dom_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-        "kernel": "gemm_f32_kernel<64,64,2,2,0,0> (v_mfma_f32_32x32x2_f32), eager launches: wav2vec2 + AdaLN table",
+        "frac": round(dom_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        "kernel": "gemm_f32_kernel<128,128,2,2,16,0,0> (v_mfma_f32_32x32x2_f32): every launch of it (wav2vec2 conv/encoder GEMMs, AdaLN table)",
+        "measured_ceiling": 147.9,   # register-only MFMA loop on this chip, profiles/r01_mfma_peak.log,
         "launches": int(prof["dom_launches"]), "avg_launch_ms": round(prof["dom_ms"] / max(prof["dom_launches"], 1), 4),
         "share_of_step_ms": round(prof["dom_ms"], 2),
     }

@@ -94,7 +94,7 @@ int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, v
  * LAST artalk_infer's numbers (milliseconds / counters):
  *   out[0] style  out[1] wav2vec2 conv stack  out[2] wav2vec2 encoder  out[3] AdaLN table GEMM
  *   out[4] AR scale steps (level 1: whole captured body)  out[5] VAE decode+re-encode (level 2 only; + initial history)
- *   out[6] total  out[7] bracketed launches of the dominant kernel (64x64-tile fp32 MFMA GEMM)  out[8] their summed ms
+ *   out[6] total  out[7] bracketed launches of the dominant kernel (128x128-tile fp32 MFMA GEMM)  out[8] their summed ms
  *   out[9] their summed FLOP */
 int artalk_set_profiling(artalk_model* m, int level);
 int artalk_get_profile(artalk_model* m, double* out, int n);
@@ -105,9 +105,11 @@ int artalk_set_graphs(artalk_model* m, int enable);
 /* C[M,N] = R + gate * act(A[M,K] W[N,K]^T + bias); act: 0 none, 1 gelu(erf), 2 gelu(tanh), 3 leaky_relu(0.2). K % 32 == 0 */
 int artalk_op_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* gate, const float* R,
                    float* C, int M, int N, int K, int act, void* stream);
-/* same, with an explicit tile configuration (0: 128x128, 1: 128x64, 2: 64x64, 3: 32x128; -1: heuristic) for tuning */
+/* same, with an explicit tile configuration (4: 128x128 BK16, 2: 64x64, 1: 128x64, 3: 32x128, 0/5/6/7: tuning variants; -1: heuristic) for tuning */
 int artalk_op_gemm_ex(const float* A, int64_t lda, const float* W, const float* bias, float* C, int M, int N, int K, int act,
                       int force_cfg, void* stream);
+/* calibration: register-only fp32 MFMA loop (blocks x 256 threads, 32*iters MFMAs per wave, nacc = 1 or 4 independent accumulators); *flops = FLOPs of the launch */
+int artalk_op_mfma_f32_peak(float* out_dev, int blocks, int iters, int nacc, double* flops, void* stream);
 /* y = LN(x)[*w+b][*(1+scale)+shift][act], D in {128,512,768,1024} */
 int artalk_op_layernorm(const float* X, float* Y, const float* w, const float* b, const float* scale, const float* shift,
                         int M, int D, float eps, int act, void* stream);

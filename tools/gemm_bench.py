@@ -13,7 +13,18 @@ SHAPES = [  # (name, M, N, K)
     ("ar qkv p2", 800, 2304, 768), ("ar ffn2 p2", 800, 768, 3072), ("ar qkv p0", 32, 2304, 768), ("ar ffn2 p0", 32, 768, 3072),
     ("vae qkv", 6400, 1536, 512), ("vae out", 6400, 512, 512),
 ]
+only = os.environ.get("GEMM_ONLY")
+if only:
+    SHAPES = [x for x in SHAPES if x[0] in only.split(",")]
 cfgs = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3".split(","))]
+# correctness of every requested configuration on an awkward shape first
+A = torch.randn(777, 96, device='cuda'); W = torch.randn(333, 96, device='cuda'); b = torch.randn(333, device='cuda')
+ref = (A.double() @ W.double().t() + b.double()).float()
+for cfg in cfgs:
+    Cc = torch.zeros(777, 333, device='cuda')
+    L.artalk_op_gemm_ex(p(A), 96, p(W), p(b), p(Cc), 777, 333, 96, 0, cfg, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    print(f'cfg{cfg} max err {float((Cc - ref).abs().max()):.2e}', flush=True)
 for name, M, N, K in SHAPES:
     A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.03; b = torch.randn(N, device="cuda")
     Cc = torch.empty(M, N, device="cuda")

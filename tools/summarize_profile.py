@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 output directories (gpurun_out/...) into the small summaries kept under profiles/.
+
+  summarize_profile.py stats  <dir> <out.csv>            kernel-trace --stats: the per-kernel table
+  summarize_profile.py pmc    <fetch_dir> <write_dir> <out.json>   FETCH_SIZE / WRITE_SIZE passes -> bytes per launch
+
+HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
+exactly half of a wide (16 B/lane) coalesced read stream, so reads = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def find(d, pat):
+    f = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    assert f, (d, pat)
+    return f[0]
+
+
+def short(name):
+    name = name.replace("void ", "").replace("artalk::", "")
+    return name.split("(")[0][:70]
+
+
+def stats(d, out):
+    rows = list(csv.DictReader(open(find(d, "*kernel_stats.csv"))))
+    with open(out, "w") as f:
+        f.write("kernel,calls,total_ms,avg_us,min_us,max_us,pct\n")
+        for r in rows[:24]:
+            f.write(f"\"{short(r['Name'])}\",{r['Calls']},{float(r['TotalDurationNs']) / 1e6:.3f},{float(r['AverageNs']) / 1e3:.2f},"
+                    f"{float(r['MinNs']) / 1e3:.2f},{float(r['MaxNs']) / 1e3:.2f},{float(r['Percentage']):.3f}\n")
+    print(open(out).read())
+
+
+def pmc(fd, wd, out):
+    res = collections.defaultdict(dict)
+    for tag, d in (("FETCH_SIZE", fd), ("WRITE_SIZE", wd)):
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(find(d, "*counter_collection.csv"))):
+            if r["Counter_Name"] != tag:
+                continue
+            k = short(r["Kernel_Name"])
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+        for k, (n, v) in agg.items():
+            res[k][tag + "_KiB_per_launch"] = v / n
+            res[k]["launches_" + tag] = n
+    outd = {}
+    for k, v in res.items():
+        if "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
+            v["hbm_read_bytes_per_launch"] = 2.0 * v["FETCH_SIZE_KiB_per_launch"] * 1024
+            v["hbm_write_bytes_per_launch"] = v["WRITE_SIZE_KiB_per_launch"] * 1024
+            v["hbm_bytes_per_launch"] = v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]
+            outd[k] = v
+    top = dict(sorted(outd.items(), key=lambda t: -t[1]["hbm_bytes_per_launch"] * t[1]["launches_FETCH_SIZE"])[:12])
+    json.dump(top, open(out, "w"), indent=1)
+    for k, v in top.items():
+        print(f"{k:70s} launches={v['launches_FETCH_SIZE']:5d} read={v['hbm_read_bytes_per_launch'] / 1e6:9.1f} MB write={v['hbm_write_bytes_per_launch'] / 1e6:9.1f} MB")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
