@@ -21,7 +21,7 @@ SYMBOLS = [
     "artalk_create", "artalk_destroy", "artalk_last_error", "artalk_set_tensor", "artalk_finalize_weights",
     "artalk_reserve", "artalk_workspace_bytes", "artalk_weight_bytes", "artalk_infer", "artalk_savgol",
     "artalk_set_profiling", "artalk_get_profile", "artalk_set_graphs",
-    "artalk_op_gemm", "artalk_op_gemm_ex", "artalk_op_mfma_f32_peak", "artalk_op_layernorm", "artalk_op_attention", "artalk_op_w2v_front", "artalk_op_pool_silu",
+    "artalk_op_gemm", "artalk_op_gemm_ex", "artalk_op_mfma_f32_peak", "artalk_op_layernorm", "artalk_op_attention", "artalk_op_w2v_front", "artalk_op_resample_mean", "artalk_op_pool_silu",
     "artalk_op_bsq_history",
 ]
 
@@ -120,6 +120,8 @@ def lib() -> C.CDLL:
     L.artalk_op_attention.restype = i32
     L.artalk_op_w2v_front.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.artalk_op_w2v_front.restype = i32
+    L.artalk_op_resample_mean.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, i32, vp]
+    L.artalk_op_resample_mean.restype = i32
     L.artalk_op_pool_silu.argtypes = [vp, i32, i32, i32, vp, vp]
     L.artalk_op_pool_silu.restype = i32
     L.artalk_op_bsq_history.argtypes = [vp, vp, vp, vp, i32, vp]

@@ -960,6 +960,13 @@ int artalk_op_w2v_front(const float* audio, int C, int n, const float* w, const 
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }
 
+int artalk_op_resample_mean(const float* x, int nch, int n, const float* taps, int orig, int nw, int width, float* out, int n_out,
+                            void* stream) {
+    if (!x || !taps || !out || nch <= 0 || n <= 0 || orig <= 0 || nw <= 0 || width < 0) return ARTALK_EINVAL;
+    launch_resample_mean(x, nch, n, taps, orig, nw, width, out, n_out, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+}
+
 int artalk_op_pool_silu(const float* X, int C, int T, int D, float* Y, void* stream) {
     if (!X || !Y || D % 4 != 0) return ARTALK_EINVAL;
     static const int pn[5] = {1, 5, 25, 50, 100};

@@ -110,6 +110,9 @@ void launch_add_row(float* X, const float* v, int M, int D, hipStream_t s);
 void launch_savgol(const float* in, float* out, int T, int D, hipStream_t s);
 
 double launch_mfma_f32_peak(float* out, int blocks, int iters, int nacc, hipStream_t s);   // calibration kernel, returns FLOPs
+// sinc resampler + channel mean: x [nch][n] -> out [n_out], taps [new][2*width+orig]
+void launch_resample_mean(const float* x, int nch, int n, const float* taps, int orig, int nw, int width, float* out, int n_out,
+                          hipStream_t s);
 void init_ms_tables();   // uploads the (tiny) interpolation tables to __constant__ memory; idempotent
 
 }  // namespace artalk

@@ -137,3 +137,36 @@ void launch_pool_silu(const float* X, int x_tstride, int T, float* Y, int n_chun
 }
 
 }  // namespace artalk
+
+// ------------------------------------------------------------------------------------------------
+// torchaudio-style polyphase sinc resampler + channel mean (reference inference.py:230-231): output frame i = j*new + p
+// is sum_k taps[p][k] * xpad[j*orig + k] with xpad = x zero-padded by `width` on the left; mean over channels afterwards.
+// HBM-bound FIR (48k stereo -> 16k mono: 24 B in, 4 B out per output sample, 41 taps served from L1/L2).
+namespace artalk {
+__global__ __launch_bounds__(256) void resample_mean_kernel(const float* __restrict__ x, int nch, int n, const float* __restrict__ taps,
+                                                            int orig, int nw, int width, float* __restrict__ out, int n_out) {
+    const int ntaps = 2 * width + orig;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_out; i += gridDim.x * 256) {
+        const int j = i / nw, p = i - j * nw;
+        const float* tp = taps + (long)p * ntaps;
+        const long base = (long)j * orig - width;
+        float acc = 0.f;
+        for (int c = 0; c < nch; ++c) {
+            const float* xc = x + (long)c * n;
+            float s = 0.f;
+            for (int k = 0; k < ntaps; ++k) {
+                const long t = base + k;
+                if (t >= 0 && t < n) s = fmaf(tp[k], xc[t], s);
+            }
+            acc += s;
+        }
+        out[i] = acc / (float)nch;
+    }
+}
+void launch_resample_mean(const float* x, int nch, int n, const float* taps, int orig, int nw, int width, float* out, int n_out,
+                          hipStream_t s) {
+    if (n_out <= 0) return;
+    const int blocks = (n_out + 255) / 256;
+    hipLaunchKernelGGL(resample_mean_kernel, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, s, x, nch, n, taps, orig, nw, width, out, n_out);
+}
+}  // namespace artalk

@@ -119,6 +119,10 @@ int artalk_op_attention(const float* Q, const float* K, const float* V, float* O
 /* audio [C][n] -> normalised -> conv0+LN+GELU: Y [C][T][512], T = (n-10)/5+1 */
 int artalk_op_w2v_front(const float* audio, int C, int n, const float* w, const float* bias, const float* lnw,
                         const float* lnb, float* xnorm_out, float* Y, void* stream);
+/* audio front-end of inference.py:230-231: polyphase sinc FIR (torchaudio Resample defaults) + mean over channels.
+ * x [nch][n] f32, taps [nw][2*width+orig] f32 (host-built, see artalk_amd/audio.py), out [n_out], n_out = ceil(n*nw/orig) */
+int artalk_op_resample_mean(const float* x, int nch, int n, const float* taps, int orig, int nw, int width, float* out, int n_out,
+                            void* stream);
 /* X [C][T][D] -> Y [C][181][D]: area pooling to {1,5,25,50,100} then SiLU */
 int artalk_op_pool_silu(const float* X, int C, int T, int D, float* Y, void* stream);
 /* enc_out [B][100][32] -> hist_bits [B][181][32] u8, prev_fdec [B][100][32], msfeat [B][180][32] */

@@ -64,8 +64,8 @@ def load_reference_model(cfg: ARTalkConfig, sd):
     return model
 
 
-def run_case(model, sd, seed, seconds, with_style):
-    audio = torch.from_numpy(synth_audio(seed, seconds))[None]
+def run_case(model, sd, seed, seconds, with_style, audio_np=None):
+    audio = torch.from_numpy(synth_audio(seed, seconds) if audio_np is None else audio_np)[None]
     style = None
     if with_style:
         style = torch.from_numpy(synth_style(seed, sd["basic_vae.motion_mean"].numpy(), sd["basic_vae.motion_std"].numpy()))[None]
@@ -114,10 +114,41 @@ def run_case(model, sd, seed, seconds, with_style):
     )
 
 
+DEMO = [("eng1", 4, True), ("eng2", 5, False)]     # (demo/<name>.wav, style seed, with style)
+
+
+def demo_cases(model, sd, fp, out_dir):
+    """Real speech (configs 1 and 5 of BASELINE.json): demo/*.wav -> 16 kHz mono with this repo's restatement of the
+    torchaudio resampler (oracle/audio_oracle.py), quantised to int16 so the input itself is a small committed fixture
+    (tests/golden/demo_16k_s16.npz); the reference then runs on exactly that array."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from audio_oracle import load_mono_16k
+    from artalk_amd.audio import read_wav
+    inputs = {}
+    for name, seed, with_style in DEMO:
+        wav, sr = read_wav(os.path.join(REFERENCE, "demo", name + ".wav"))
+        a = load_mono_16k(wav, sr).numpy()
+        q = np.clip(np.round(a * 32768.0), -32768, 32767).astype(np.int16)
+        inputs[name] = q
+        audio = (q.astype(np.float32) / np.float32(32768.0))
+        g = run_case(model, sd, seed, len(q) / 16000.0, with_style, audio_np=audio)
+        g["weights_seed"] = np.int64(DEFAULT_SEED)
+        g["weights_fingerprint_keys"] = np.array(list(fp.keys()))
+        g["weights_fingerprint"] = np.array([fp[k] for k in fp], dtype=np.float64)
+        g["demo"] = np.array(name)
+        path = os.path.join(out_dir, f"full_demo_{name}.npz")
+        np.savez_compressed(path, **g)
+        print(f"  full_demo_{name}: frames={g['out'].shape[0]} min logit margin={g['logit_margin'].min():.2e} "
+              f"min hist margin={g['hist_margin'].min():.2e} -> {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+    np.savez_compressed(os.path.join(out_dir, "demo_16k_s16.npz"), **inputs)
+    print("  demo inputs ->", os.path.getsize(os.path.join(out_dir, "demo_16k_s16.npz")) // 1024, "KiB", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", default="tiny,full")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only-demo", action="store_true")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
@@ -131,7 +162,7 @@ def main():
         print(f"[{cfg_name}] reference constructed + strict load in {time.time() - t0:.1f}s", flush=True)
         fp = fingerprint(sd)
         for name, c, seed, seconds, with_style in CASES:
-            if c != cfg_name:
+            if c != cfg_name or args.only_demo:
                 continue
             g = run_case(model, sd, seed, seconds, with_style)
             g["weights_seed"] = np.int64(DEFAULT_SEED)
@@ -143,6 +174,8 @@ def main():
             print(f"  {name}: frames={g['out'].shape[0]} ref_time={float(g['ref_seconds']):.2f}s "
                   f"min logit margin={g['logit_margin'].min():.2e} min hist margin={g['hist_margin'].min():.2e} "
                   f"-> {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+        if cfg_name == "full":
+            demo_cases(model, sd, fp, args.out)
         del model, sd
 
 

@@ -58,9 +58,14 @@ def load_golden(case):
 
 def golden_inputs(g, sd):
     """Rebuild the inputs of a golden case from its seeds."""
+    import numpy as np
     import torch
     from artalk_amd.synth import synth_audio, synth_style
-    audio = torch.from_numpy(synth_audio(int(g["seed"]), float(g["seconds"])))
+    if "demo" in g.files:      # real speech: the committed 16 kHz int16 array is the input definition
+        q = np.load(os.path.join(GOLDEN, "demo_16k_s16.npz"))[str(g["demo"])]
+        audio = torch.from_numpy(q.astype(np.float32) / np.float32(32768.0))
+    else:
+        audio = torch.from_numpy(synth_audio(int(g["seed"]), float(g["seconds"])))
     style = None
     if bool(g["with_style"]):
         style = torch.from_numpy(synth_style(int(g["seed"]), sd["basic_vae.motion_mean"].numpy(), sd["basic_vae.motion_std"].numpy()))

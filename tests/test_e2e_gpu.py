@@ -18,7 +18,8 @@ TAU_HIST = 2e-5      # |z| (unit-normalised) of the reference at a legitimately 
 FLAME_TOL = 1e-3
 LEVEL_OF = np.concatenate([np.full(p, i) for i, p in enumerate((1, 5, 25, 50, 100))])
 
-CASES = ["tiny_4s_s0", "tiny_10s_s1_style", "tiny_6p3s_s2", "full_10s_s0", "full_10s_s1_style", "full_4s_s2", "full_5p5s_s3_style"]
+CASES = ["tiny_4s_s0", "tiny_10s_s1_style", "tiny_6p3s_s2", "full_10s_s0", "full_10s_s1_style", "full_4s_s2", "full_5p5s_s3_style",
+         "full_demo_eng1", "full_demo_eng2"]     # the last two: real speech (reference demo/*.wav), 4 chunks / 1 chunk
 
 
 def first_flip(mine, gold, margin, tau):
