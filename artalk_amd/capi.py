@@ -20,8 +20,8 @@ DTYPE_F32, DTYPE_I64 = 0, 1
 SYMBOLS = [
     "artalk_create", "artalk_destroy", "artalk_last_error", "artalk_set_tensor", "artalk_finalize_weights",
     "artalk_reserve", "artalk_workspace_bytes", "artalk_weight_bytes", "artalk_infer", "artalk_savgol",
-    "artalk_set_profiling", "artalk_get_profile", "artalk_set_graphs",
-    "artalk_op_gemm", "artalk_op_gemm_ex", "artalk_op_mfma_f32_peak", "artalk_op_layernorm", "artalk_op_attention", "artalk_op_w2v_front", "artalk_op_resample_mean", "artalk_op_pool_silu",
+    "artalk_set_profiling", "artalk_get_profile", "artalk_set_graphs", "artalk_set_precision",
+    "artalk_op_gemm", "artalk_op_gemm_ex", "artalk_op_gemm_f16s", "artalk_op_mfma_f32_peak", "artalk_op_layernorm", "artalk_op_attention", "artalk_op_w2v_front", "artalk_op_resample_mean", "artalk_op_pool_silu",
     "artalk_op_bsq_history",
 ]
 
@@ -110,6 +110,10 @@ def lib() -> C.CDLL:
     L.artalk_set_graphs.restype = i32
     L.artalk_op_gemm.argtypes = [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.artalk_op_gemm.restype = i32
+    L.artalk_set_precision.argtypes = [vp, i32]
+    L.artalk_set_precision.restype = i32
+    L.artalk_op_gemm_f16s.argtypes = [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.artalk_op_gemm_f16s.restype = i32
     L.artalk_op_gemm_ex.argtypes = [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.artalk_op_gemm_ex.restype = i32
     L.artalk_op_mfma_f32_peak.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_double), vp]

@@ -83,6 +83,9 @@ struct artalk_model {
     std::vector<void*> allocs;      // weights (model lifetime)
     std::vector<void*> ws_allocs;   // workspace (re-allocated when a larger batch arrives)
     int64_t weight_bytes = 0;
+    struct PackRange { const float* base; int64_t n; unsigned int* packed; };
+    std::vector<PackRange> wranges;   // every weight allocation and its packed f16x3 copy (built at finalize)
+    int precision = 0;                // 0: fp32 MFMA everywhere, 1: f16x3 split GEMMs (heads stay fp32)
     // derived sizes
     int n_conv = 0; int conv_T[8]{}; int conv_S[8]{};   // valid frames / padded row stride per conv layer output
     int Tw = 0, Ts = 0;                                 // 199, 200
@@ -143,7 +146,15 @@ T* dalloc(artalk_model* m, int64_t n) { return dalloc_in<T>(m->allocs, n); }
 
 float* walloc(artalk_model* m, int64_t n) {
     m->weight_bytes += n * 4;
-    return dalloc<float>(m, n);
+    float* p = dalloc<float>(m, n);
+    m->wranges.push_back({p, n, nullptr});
+    return p;
+}
+
+const unsigned int* packed_of(const artalk_model* m, const float* w) {
+    for (const auto& r : m->wranges)
+        if (r.packed && w >= r.base && w < r.base + r.n) return r.packed + (w - r.base);
+    return nullptr;
 }
 
 void add_slot(artalk_model* m, const std::string& key, std::vector<int64_t> shape, SlotKind kind, float* dst,
@@ -328,21 +339,26 @@ void stage_mark(artalk_model* m, hipStream_t s, int bucket) {
 void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
     GemmArgs g = g0;
     g.graph_tag = m->in_body ? 1 : 0;
-    if (m->profiling && !m->in_body && gemm_config(g) == 4 && g.M > 0) {
-        size_t i0, i1;
-        next_event(m, s, &i0);
-        launch_gemm(g, s);
+    bool split = false;
+    if (m->precision == 1 && !g.exact) {
+        g.Wp = packed_of(m, g.W);
+        split = gemm_f16s_eligible(g);
+    }
+    const bool dominant = !m->in_body && g.M > 0 && (split ? gemm_f16s_config(g) == 0 : gemm_config(g) == 4);
+    size_t i0 = 0, i1 = 0;
+    if (m->profiling && dominant) next_event(m, s, &i0);
+    if (split) launch_gemm_f16s(g, s); else launch_gemm(g, s);
+    if (m->profiling && dominant) {
         next_event(m, s, &i1);
         m->dom_events.emplace_back(i0, gemm_flops(g));
-    } else {
-        launch_gemm(g, s);
     }
 }
 
 // plain y = act(x W^T + b) [+ R]
 void linear(artalk_model* m, const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N, int K,
-            int act, const float* R, hipStream_t s) {
+            int act, const float* R, hipStream_t s, int exact = 0) {
     GemmArgs g;
+    g.exact = exact;
     g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act;
     g.R = R; g.ldr = ldc;
     gemm(m, g, s);
@@ -470,7 +486,7 @@ void run_reencode(artalk_model* m, int B, hipStream_t s) {
     const int H = c.vae_hidden, T = 100;
     linear(m, w.enc_in, 128, m->enc.in_w, m->enc.in_b, w.vh, H, B * T, H, 128, ACT_LEAKY02, nullptr, s);
     run_vae_stack(m, m->enc, B, T, 0, s);
-    linear(m, w.vh, H, m->enc.out_w, m->enc.out_b, w.enc_out, c.code_dim, B * T, c.code_dim, H, ACT_NONE, nullptr, s);
+    linear(m, w.vh, H, m->enc.out_w, m->enc.out_b, w.enc_out, c.code_dim, B * T, c.code_dim, H, ACT_NONE, nullptr, s, /*exact=*/1);
     launch_bsq_history(w.enc_out, w.hist_bits, w.prev_fdec, w.msfeat, B, s);
     launch_vq_embed(w.msfeat, kNTok - 1, m->vq_w, m->vq_b, m->prev_lvl_pos + kE, w.prev_in, kNTok, 1, w.style_cond,
                     m->prev_lvl_pos, B, s);
@@ -534,7 +550,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
         nh.X = w.x; nh.ldx = kE; nh.Y = w.xmod; nh.ldy = kE; nh.scale = hada; nh.shift = hada + kE; nh.ldm = ldada; nh.mmap = amap;
         nh.M = M; nh.D = kE; nh.eps = 1e-6f;
         launch_layernorm(nh, s);
-        linear(m, w.xmod, kE, m->logits_w, m->logits_b, w.logits, 2 * c.code_dim, M, 2 * c.code_dim, kE, ACT_NONE, nullptr, s);
+        linear(m, w.xmod, kE, m->logits_w, m->logits_b, w.logits, 2 * c.code_dim, M, 2 * c.code_dim, kE, ACT_NONE, nullptr, s, /*exact=*/1);
         launch_ar_bits_next(w.logits, w.bits, w.fhat, w.nextfeat, B, p, s);
         if (p + 1 < c.n_levels)
             launch_vq_embed(w.nextfeat, m->pn[p + 1], m->vq_w, m->vq_b, m->lvl_pos + (long)m->off[p + 1] * kE, w.x, m->pn[p + 1], 0,
@@ -767,6 +783,14 @@ int artalk_finalize_weights(artalk_model* m) {
         if (int rc = upload(m, m->pos_w, t.data(), (int64_t)t.size())) return rc;
     }
     for (auto& kv : m->slots) { std::vector<float>().swap(kv.second.host); }
+    // packed f16x3 copies of every weight matrix (same size and indexing as the fp32 original)
+    for (auto& r : m->wranges) {
+        if (r.n < 1024 || r.packed) continue;
+        r.packed = dalloc<unsigned int>(m, r.n);
+        if (!r.packed) return fail(m, ARTALK_EHIP, "hipMalloc failed for packed weights");
+        launch_pack_split(r.base, r.packed, r.n, nullptr);
+    }
+    HIPCHK(m, hipDeviceSynchronize());
     m->finalized = true;
     return ARTALK_OK;
 }
@@ -780,6 +804,17 @@ int64_t artalk_workspace_bytes(const artalk_model* m) { return m ? m->ws.bytes :
 int64_t artalk_weight_bytes(const artalk_model* m) { return m ? m->weight_bytes : 0; }
 
 int artalk_set_profiling(artalk_model* m, int level) { if (!m || level < 0 || level > 2) return ARTALK_EINVAL; m->profiling = level; return ARTALK_OK; }
+int artalk_set_precision(artalk_model* m, int mode) {
+    if (!m || (mode != 0 && mode != 1)) return ARTALK_EINVAL;
+    if (mode != m->precision) {   // captured graphs hold the other mode's kernels
+        (void)hipSetDevice(m->device);
+        (void)hipDeviceSynchronize();
+        for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
+        m->graphs.clear();
+        m->precision = mode;
+    }
+    return ARTALK_OK;
+}
 int artalk_set_graphs(artalk_model* m, int enable) { if (!m) return ARTALK_EINVAL; m->use_graphs = enable != 0; return ARTALK_OK; }
 
 int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_stride, const int64_t* n_chunks, int B,
@@ -917,6 +952,23 @@ int artalk_op_gemm_ex(const float* A, int64_t lda, const float* W, const float* 
 int artalk_op_mfma_f32_peak(float* out_dev, int blocks, int iters, int nacc, double* flops, void* stream) {
     if (!out_dev || !flops || blocks <= 0 || iters <= 0) return ARTALK_EINVAL;
     *flops = launch_mfma_f32_peak(out_dev, blocks, iters, nacc, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+}
+
+// f16x3 split GEMM on fp32 inputs (W is packed into a temporary): same contract as artalk_op_gemm_ex; cfg 0: 128x128, 1: 64x64, -1: heuristic
+int artalk_op_gemm_f16s(const float* A, int64_t lda, const float* W, const float* bias, float* C, int M, int N, int K, int act,
+                        int force_cfg, void* stream) {
+    if (!A || !W || !C || K % 32 != 0 || M <= 32 || N <= 0) return ARTALK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int* wp = nullptr;
+    if (hipMalloc(&wp, (size_t)N * K * 4) != hipSuccess) return ARTALK_EHIP;
+    launch_pack_split(W, wp, (long)N * K, s);
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.Wp = wp; g.ldw = K; g.bias = bias; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
+    g.force_cfg = force_cfg;
+    launch_gemm_f16s(g, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(wp);
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }
 

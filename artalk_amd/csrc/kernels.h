@@ -27,6 +27,8 @@ enum Act { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_TANH = 2, ACT_LEAKY02 = 3 };
 struct GemmArgs {
     const float* A = nullptr; long lda = 0;
     const float* W = nullptr; long ldw = 0;
+    const unsigned int* Wp = nullptr;   // optional packed (f16 hi | f16 lo << 16) copy of W, same ld: f16x3 split path
+    int exact = 0;                       // 1: decision-critical GEMM (logit / code heads), always on the fp32 MFMA path
     const float* bias = nullptr;
     float* C = nullptr; long ldc = 0; RowMap cmap = {INT_MAX, 0, 0};
     const float* gate = nullptr; long ldg = 0; RowMap gmap = {INT_MAX, 0, 0};
@@ -42,6 +44,11 @@ struct GemmArgs {
     int graph_tag = 0;   // 1 for launches inside the captured AR/VAE body (separate kernel symbol, same code)
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);
+// fp32-accurate GEMM on the fp16 matrix cores by operand splitting (gemm_f16s.hip)
+void launch_pack_split(const float* w, unsigned int* out, long n, hipStream_t s);
+bool gemm_f16s_eligible(const GemmArgs& g);
+int gemm_f16s_config(const GemmArgs& g);     // 0: 128x128 (dominant kernel of the split mode), 1: 64x64
+void launch_gemm_f16s(const GemmArgs& g, hipStream_t s);
 int gemm_config(const GemmArgs& g);   // 4: 128x128 BK16 (dominant kernel), 2: 64x64, 1: 128x64, 3: 32x128; 0,5,6,7 tuning variants
 // Average kernel time helper for benches: FLOPs of one launch
 static inline double gemm_flops(const GemmArgs& g) { return 2.0 * g.M * (double)g.N * g.K * g.batch; }

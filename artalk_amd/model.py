@@ -147,6 +147,13 @@ class BitwiseARModel:
         """0 off, 1 light (graphs on, eager launches bracketed), 2 full (graphs off)."""
         capi.lib().artalk_set_profiling(self._h, int(level))
 
+    def set_precision(self, mode):
+        """'f32' / 0: exact fp32 MFMA (default); 'f16x3' / 1: fp16 operand-split GEMMs with fp32-class accuracy."""
+        mode = {"f32": 0, "f16x3": 1}.get(mode, mode)
+        rc = capi.lib().artalk_set_precision(self._h, int(mode))
+        if rc != capi.OK:
+            raise ValueError("precision mode must be 'f32' or 'f16x3'")
+
     def set_graphs(self, on: bool):
         capi.lib().artalk_set_graphs(self._h, int(bool(on)))
 

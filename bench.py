@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--config", default="full")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
+                    help="GEMM arithmetic: exact fp32 MFMA, or fp16 operand-split MFMA with fp32-class accuracy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=12)
     args = ap.parse_args()
@@ -91,6 +93,7 @@ def main():
     sd = generate_state_dict(cfg)
     model = BitwiseARModel(cfg).eval().to(dev)
     model.load_state_dict(sd, strict=True)
+    model.set_precision(args.precision)
     t_load = time.time() - t0
     log(f"rank {rank}: weights generated + loaded in {t_load:.1f} s")
 

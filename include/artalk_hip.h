@@ -98,6 +98,10 @@ int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, v
  *   out[9] their summed FLOP */
 int artalk_set_profiling(artalk_model* m, int level);
 int artalk_get_profile(artalk_model* m, double* out, int n);
+/* GEMM arithmetic: 0 (default) = exact fp32 on v_mfma_f32_32x32x2_f32; 1 = "f16x3": every fp32 operand split into two
+ * fp16 values (22 significand bits), three fp16 MFMA products accumulated in fp32 - fp32-class accuracy (parity tests run in
+ * both modes) at 5.3x the matrix-core rate; the logit / code heads stay on the fp32 path in both modes. */
+int artalk_set_precision(artalk_model* m, int mode);
 /* Replay the AR/VAE part from hipGraphs captured per active-batch size (default 1 = on). */
 int artalk_set_graphs(artalk_model* m, int enable);
 
@@ -110,6 +114,9 @@ int artalk_op_gemm_ex(const float* A, int64_t lda, const float* W, const float* 
                       int force_cfg, void* stream);
 /* calibration: register-only fp32 MFMA loop (blocks x 256 threads, 32*iters MFMAs per wave, nacc = 1 or 4 independent accumulators); *flops = FLOPs of the launch */
 int artalk_op_mfma_f32_peak(float* out_dev, int blocks, int iters, int nacc, double* flops, void* stream);
+/* f16x3 split GEMM (mode 1 above) on fp32 inputs; cfg 0: 128x128 tiles, 1: 64x64, -1: heuristic.  M > 32, K % 32 == 0 */
+int artalk_op_gemm_f16s(const float* A, int64_t lda, const float* W, const float* bias, float* C, int M, int N, int K, int act,
+                        int force_cfg, void* stream);
 /* y = LN(x)[*w+b][*(1+scale)+shift][act], D in {128,512,768,1024} */
 int artalk_op_layernorm(const float* X, float* Y, const float* w, const float* b, const float* scale, const float* shift,
                         int M, int D, float eps, int act, void* stream);

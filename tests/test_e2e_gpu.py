@@ -36,11 +36,14 @@ def first_flip(mine, gold, margin, tau):
     return None
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("case", CASES)
-def test_against_reference_golden(case):
+def test_against_reference_golden(case, precision):
+    """precision 'f32': exact fp32 MFMA GEMMs; 'f16x3': operand-split fp16 MFMA GEMMs (fp32-class accuracy).  Same bar."""
     g = load_golden(case)
     name = case.split("_")[0]
     m = get_gpu_model(name)
+    m.set_precision(precision)
     cfg, sd = get_state_dict(name)
     audio, style = golden_inputs(g, sd)
     out = m.inference_batch([audio], [style], return_aux=True)[0].cpu().numpy()
@@ -68,7 +71,8 @@ def test_against_reference_golden(case):
             break
     n = min(good_chunks * 100, out.shape[0])
     err = np.abs(out[:n] - g["out"][:n]).max() if n else 0.0
-    print(f"{case}: chunks exact {good_chunks}/{n_chunks}, FLAME max-abs err {err:.3e}, "
+    m.set_precision("f32")
+    print(f"{case} [{precision}]: chunks exact {good_chunks}/{n_chunks}, FLAME max-abs err {err:.3e}, "
           f"w2v err {np.abs(w2v[:, :, :16] - g['w2v_slice']).max():.3e}")
     assert err < FLAME_TOL
     # at least the first chunk must be decision-exact in every fixture (margins there are far above rounding)

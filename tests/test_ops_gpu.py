@@ -69,6 +69,29 @@ def test_gemm(M, N, K, act, use_bias, use_gate, use_res):
     assert err < 3e-5 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("M,N,K,cfg", [(1000, 512, 1536, 0), (2000, 1024, 1024, 1), (333, 768, 3072, -1), (19200, 1024, 4096, 0), (200, 106, 512, 1)])
+def test_gemm_f16x3_split_is_fp32_accurate(M, N, K, cfg):
+    """The operand-split fp16 GEMM (artalk_set_precision mode 1) against float64: its error must be at the level of an
+    exact-fp32 GEMM (accumulation rounding), far from fp16/bf16 level; also checked against the fp32-MFMA kernel."""
+    capi, L = _lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * 3.0
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    ref = (A.double() @ W.double().t() + bias.double())
+    dA, dW, db = _dev(A), _dev(W), _dev(bias)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    out32 = torch.empty(M, N, device="cuda")
+    assert L.artalk_op_gemm_f16s(_p(dA), K, _p(dW), _p(db), _p(out), M, N, K, 0, cfg, None) == 0
+    assert L.artalk_op_gemm(_p(dA), K, _p(dW), _p(db), None, None, _p(out32), M, N, K, 0, None) == 0
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    err = (out.cpu().double() - ref).abs().max().item() / scale
+    err32 = (out32.cpu().double() - ref).abs().max().item() / scale
+    print(f"f16x3 rel err {err:.2e}  fp32-mfma rel err {err32:.2e}")
+    assert err < 1.5e-6 and err < 4 * err32 + 2e-7, (err, err32)
+
+
 def test_gemm_exact_integers():
     """A = I-like and asymmetric small integers: the MFMA lane maps (no row/col swap) are exact in fp32."""
     capi, L = _lib()
