@@ -965,10 +965,33 @@ int artalk_op_gemm_f16s(const float* A, int64_t lda, const float* W, const float
     launch_pack_split(W, wp, (long)N * K, s);
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.Wp = wp; g.ldw = K; g.bias = bias; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
-    g.force_cfg = force_cfg;
+    g.force_cfg = force_cfg & 0xff;
+    unsigned int* ap = nullptr;
+    if (force_cfg >= 0 && (force_cfg & 0x100)) {   // tuning: pre-packed A (what a fused producer would hand over)
+        if (hipMalloc(&ap, (size_t)M * lda * 4) != hipSuccess) return ARTALK_EHIP;
+        launch_pack_split(A, ap, (long)M * lda, s);
+        g.A = reinterpret_cast<const float*>(ap); g.a_packed = 1;
+    }
     launch_gemm_f16s(g, s);
     (void)hipStreamSynchronize(s);
     (void)hipFree(wp);
+    if (ap) (void)hipFree(ap);
+    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+}
+
+// building blocks for tuning the split GEMM without allocation noise: pack once, then launch on packed operands
+int artalk_op_pack_split(const float* in, void* out_u32, int64_t n, void* stream) {
+    if (!in || !out_u32 || n <= 0) return ARTALK_EINVAL;
+    launch_pack_split(in, (unsigned int*)out_u32, n, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+}
+int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const void* Wp, const float* bias, float* C, int M, int N,
+                               int K, int act, int force_cfg, void* stream) {
+    if (!A || !Wp || !C || K % 32 != 0 || M <= 32 || N <= 0) return ARTALK_EINVAL;
+    GemmArgs g;
+    g.A = (const float*)A; g.a_packed = a_packed; g.lda = lda; g.W = nullptr; g.Wp = (const unsigned int*)Wp; g.ldw = K; g.bias = bias;
+    g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act; g.force_cfg = force_cfg;
+    launch_gemm_f16s(g, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }
 

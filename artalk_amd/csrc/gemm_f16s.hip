@@ -58,7 +58,7 @@ void launch_pack_split(const float* w, unsigned int* out, long n, hipStream_t s)
     hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, w, out, n);
 }
 
-template <int BM, int BN, int WM, int WN, int TAG>
+template <int BM, int BN, int WM, int WN, int APK, int TAG>
 __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
     constexpr int BK = 32;
     constexpr int ROWB = 144;                      // bytes per LDS row: 64 (hi) + 64 (lo) + 16 pad
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
     const float* __restrict__ A = g.A;
     const unsigned int* __restrict__ Wp = g.Wp;
 
-    f32x4 ra[A_LD];
+    u32x4 ra[A_LD];   // fp32 bits (APK=0: split while staging) or packed (hi | lo<<16) words (APK=1: producer already split)
     u32x4 rb[B_LD];
     const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
 
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const int gm = m0 + lrow + i * 32;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gm < g.M) v = *reinterpret_cast<const f32x4*>(A + (long)gm * g.lda + k);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (gm < g.M) v = *reinterpret_cast<const u32x4*>(A + (long)gm * g.lda + k);
             ra[i] = v;
         }
 #pragma unroll
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             u32x2 hi, lo;
-            split_f32x4(ra[i], hi, lo);
+            if (APK) unpack_x4(ra[i], hi, lo); else split_f32x4(__builtin_bit_cast(f32x4, ra[i]), hi, lo);
             unsigned char* p = As + (buf * BM + lrow + i * 32) * ROWB + lc4 * 2;
             *reinterpret_cast<u32x2*>(p) = hi;
             *reinterpret_cast<u32x2*>(p + 64) = lo;
@@ -204,10 +204,13 @@ template <int BM, int BN, int WM, int WN>
 static void launch_f16s_cfg(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     const size_t lds = 2 * (BM + BN) * 144;
-    if (g.graph_tag)
-        hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 1>), dim3(tiles), dim3(256), lds, s, g);
-    else
-        hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 0>), dim3(tiles), dim3(256), lds, s, g);
+    if (g.a_packed) {
+        if (g.graph_tag) hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 1, 1>), dim3(tiles), dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 1, 0>), dim3(tiles), dim3(256), lds, s, g);
+    } else {
+        if (g.graph_tag) hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 0, 1>), dim3(tiles), dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 0, 0>), dim3(tiles), dim3(256), lds, s, g);
+    }
 }
 
 // 0: 128x128 (dominant kernel of the split mode), 1: 64x64

@@ -28,6 +28,7 @@ struct GemmArgs {
     const float* A = nullptr; long lda = 0;
     const float* W = nullptr; long ldw = 0;
     const unsigned int* Wp = nullptr;   // optional packed (f16 hi | f16 lo << 16) copy of W, same ld: f16x3 split path
+    int a_packed = 0;                    // 1: A already holds packed split words (written by a producer kernel), f16x3 path only
     int exact = 0;                       // 1: decision-critical GEMM (logit / code heads), always on the fp32 MFMA path
     const float* bias = nullptr;
     float* C = nullptr; long ldc = 0; RowMap cmap = {INT_MAX, 0, 0};

@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""Throughput of the f16x3 split GEMM per shape: tile cfg 0 (128x128) / 1 (64x64) x {fp32 A split in-kernel, pre-packed A}."""
+import ctypes as C, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from artalk_amd import capi
+L = capi.lib()
+p = lambda t: C.c_void_p(t.data_ptr())
+SHAPES = [("w2v qkv", 19200, 3072, 1024), ("w2v out", 19200, 1024, 1024), ("w2v ff1", 19200, 4096, 1024), ("w2v ff2", 19200, 1024, 4096),
+          ("conv1", 614400, 512, 1536), ("ada", 5792, 56832, 1024), ("ar ffn1 p4", 3200, 3072, 768), ("ar ffn2 p4", 3200, 768, 3072),
+          ("ar qkv p2", 800, 2304, 768), ("ar ffn2 p2", 800, 768, 3072)]
+variants = [(0, 0), (0, 1), (1, 0), (1, 1)]
+s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+for name, M, N, K in SHAPES:
+    A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.03; b = torch.randn(N, device="cuda")
+    Ap = torch.empty(M, K, dtype=torch.int32, device="cuda"); Wp = torch.empty(N, K, dtype=torch.int32, device="cuda")
+    L.artalk_op_pack_split(p(A), p(Ap), M * K, s); L.artalk_op_pack_split(p(W), p(Wp), N * K, s)
+    Cc = torch.empty(M, N, device="cuda")
+    line = f"{name:12s} M={M:6d} N={N:5d} K={K:4d} "
+    for cfg, apk in variants:
+        best = 1e9
+        n = 3 if M * N * K > 1e11 else 10
+        for rnd in range(3):
+            a = Ap if apk else A
+            L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wp), p(b), p(Cc), M, N, K, 0, cfg, s)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wp), p(b), p(Cc), M, N, K, 0, cfg, s)
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / n)
+        line += f"| cfg{cfg}{'P' if apk else ' '}: {best*1e3:8.1f} us {2*M*N*K/best/1e9:6.1f} TF "
+    print(line, flush=True)
