@@ -63,6 +63,7 @@ struct Workspace {
     float *ada = nullptr, *style_cond = nullptr, *prev_in = nullptr, *cache = nullptr;
     float *x = nullptr, *xmod = nullptr, *attn_out = nullptr, *ffn_h = nullptr, *logits = nullptr;
     float *fhat = nullptr, *nextfeat = nullptr;
+    float* splitk = nullptr; int64_t splitk_floats = 0;   // partial sums of split-K GEMMs
     uint8_t *bits = nullptr, *hist_bits = nullptr, *has_style = nullptr;
     // VAE
     float *prev_fdec = nullptr, *msfeat = nullptr, *dec_x = nullptr, *vh = nullptr, *vln = nullptr, *vqkv = nullptr;
@@ -344,10 +345,20 @@ void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
         g.Wp = packed_of(m, g.W);
         split = gemm_f16s_eligible(g);
     }
+    // split-K for grids that would leave most CUs idle (small-M scale steps): S workgroups per output tile
+    if (g.batch == 1 && g.amode == 0 && m->ws.splitk && g.K >= 256) {
+        const int tiles = gemm_tile_count(g, split);
+        if (tiles < 192) {
+            int S = std::min(std::min(g.K / 64, (384 + tiles - 1) / tiles), 16);
+            while (S > 1 && (int64_t)S * g.M * g.N > m->ws.splitk_floats) --S;
+            if (S > 1) { g.splitk = S; g.partial = m->ws.splitk; }
+        }
+    }
     const bool dominant = !m->in_body && g.M > 0 && (split ? gemm_f16s_config(g) == 0 : gemm_config(g) == 4);
     size_t i0 = 0, i1 = 0;
     if (m->profiling && dominant) next_event(m, s, &i0);
     if (split) launch_gemm_f16s(g, s); else launch_gemm(g, s);
+    if (g.splitk > 1) launch_splitk_reduce(g, s);
     if (m->profiling && dominant) {
         next_event(m, s, &i1);
         m->dom_events.emplace_back(i0, gemm_flops(g));
@@ -598,6 +609,7 @@ int reserve(artalk_model* m, int maxB, int maxC) {
     w.cache = F((int64_t)c.ar_depth * maxB * 2 * kNTok * 3 * kE);
     w.x = F((int64_t)maxB * 100 * kE); w.xmod = F((int64_t)maxB * 100 * kE); w.attn_out = F((int64_t)maxB * 100 * kE);
     w.ffn_h = F((int64_t)maxB * 100 * 4 * kE); w.logits = F((int64_t)maxB * 100 * 2 * c.code_dim);
+    w.splitk_floats = (int64_t)8 << 20; w.splitk = F(w.splitk_floats);
     w.fhat = F((int64_t)maxB * 100 * c.code_dim); w.nextfeat = F((int64_t)maxB * 100 * c.code_dim);
     w.bits = dalloc_in<uint8_t>(m->ws_allocs, (int64_t)maxB * kNTok * c.code_dim);
     w.hist_bits = dalloc_in<uint8_t>(m->ws_allocs, (int64_t)maxB * kNTok * c.code_dim);

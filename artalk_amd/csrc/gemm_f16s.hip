@@ -139,12 +139,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) { accm[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
 
-    const int nk = g.K / BK;
-    gload(0);
+    const int nk_all = g.K / BK;   // split-K: this workgroup owns K steps [kt0, nk)
+    const int kt0 = (int)((long)nk_all * blockIdx.y / g.splitk), nk = (int)((long)nk_all * (blockIdx.y + 1) / g.splitk);
+    gload(kt0);
     lstore(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int buf = (kt - kt0) & 1;
         if (kt + 1 < nk) gload(kt + 1);
         const unsigned char* as = As + (buf * BM + wm * (BM / WM) + r) * ROWB + h * 16;
         const unsigned char* bs = Bs + (buf * BN + wn * (BN / WN) + r) * ROWB + h * 16;
@@ -174,6 +175,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
         __syncthreads();
     }
 
+    if (g.splitk > 1) {   // raw partial sums; the epilogue runs in splitk_reduce_kernel
+        float* __restrict__ P = g.partial + (long)blockIdx.y * g.M * g.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / WN) + j * 32 + r;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (row < g.M && col < g.N) P[(long)row * g.N + col] = accm[i][j][e] + accx[i][j][e] * kLoInv;
+                }
+        }
+        return;
+    }
     const float* __restrict__ bias = g.bias;
     float* __restrict__ C = g.C;
     const float* R = g.R;
@@ -205,11 +221,11 @@ static void launch_f16s_cfg(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     const size_t lds = 2 * (BM + BN) * 144;
     if (g.a_packed) {
-        if (g.graph_tag) hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 1, 1>), dim3(tiles), dim3(256), lds, s, g);
-        else hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 1, 0>), dim3(tiles), dim3(256), lds, s, g);
+        if (g.graph_tag) hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 1, 1>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 1, 0>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
     } else {
-        if (g.graph_tag) hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 0, 1>), dim3(tiles), dim3(256), lds, s, g);
-        else hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 0, 0>), dim3(tiles), dim3(256), lds, s, g);
+        if (g.graph_tag) hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 0, 1>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 0, 0>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
     }
 }
 
@@ -221,7 +237,7 @@ int gemm_f16s_config(const GemmArgs& g) {
 }
 
 bool gemm_f16s_eligible(const GemmArgs& g) {
-    return g.Wp != nullptr && g.amode == 0 && g.batch == 1 && g.K % 32 == 0 && g.M > 32;
+    return g.Wp != nullptr && g.amode == 0 && g.batch == 1 && g.K % 32 == 0;
 }
 
 void launch_gemm_f16s(const GemmArgs& g, hipStream_t s) {

@@ -106,12 +106,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = g.K / BK;   // K % 32 == 0 is required by the callers, so this holds for BK = 16 and 32
-    gload(0);
+    // K % 32 == 0 is required by the callers, so K / BK is exact for BK = 16 and 32; split-K: this workgroup owns K steps [kt0, kt1)
+    const int nk_all = g.K / BK;
+    const int kt0 = (int)((long)nk_all * blockIdx.y / g.splitk), nk = (int)((long)nk_all * (blockIdx.y + 1) / g.splitk);
+    gload(kt0);
     lstore(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int buf = (kt - kt0) & 1;
         if (kt + 1 < nk) gload(kt + 1);
         const float* as = As + (buf * BM + wm * (BM / WM) + r) * LDS_LD + h * (BK / 2);
         const float* bs = Bs + (buf * BN + wn * (BN / WN) + r) * LDS_LD + h * (BK / 2);
@@ -138,6 +140,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+    if (g.splitk > 1) {   // raw partial sums; bias/act/gate/residual are applied by splitk_reduce_kernel
+        float* __restrict__ P = g.partial + (long)blockIdx.y * g.M * g.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / WN) + j * 32 + r;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (row < g.M && col < g.N) P[(long)row * g.N + col] = acc[i][j][e];
+                }
+        }
+        return;
+    }
     const float* __restrict__ bias = g.bias ? g.bias + z * g.sBias : nullptr;
     float* __restrict__ C = g.C + z * g.sC;
     const float* R = g.R ? g.R + z * g.sR : nullptr;
@@ -168,7 +185,7 @@ template <int BM, int BN, int WM, int WN, int BK = 32>
 static void launch_cfg(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     const size_t lds = 2 * (BM + BN) * (BK + 4) * sizeof(float);
-    dim3 grid(tiles, 1, g.batch);
+    dim3 grid(tiles, g.splitk, g.batch);
     if (g.amode == 0 && g.graph_tag && BM == 64 && BN == 64)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, 0, 1>), grid, dim3(256), lds, s, g);
     else if (g.amode == 0)
@@ -210,6 +227,51 @@ void launch_gemm(const GemmArgs& g, hipStream_t s) {
     }
 }
 
+}  // namespace artalk
+
+// ---- split-K epilogue pass: C = R + gate * act(sum_y partial[y] + bias), partials added in y order (deterministic)
+namespace artalk {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
+    const long total = (long)g.M * g.N;
+    for (long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 4; idx < total; idx += (long)gridDim.x * 1024) {
+        const int row = (int)(idx / g.N), col0 = (int)(idx - (long)row * g.N);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool vec = (g.N % 4 == 0);
+        const int nv = vec ? 4 : min(4, (int)(total - idx));
+        for (int y = 0; y < g.splitk; ++y) {
+            const float* P = g.partial + (long)y * total + idx;
+            if (vec) { const f32x4 t = *reinterpret_cast<const f32x4*>(P); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+            else for (int e = 0; e < nv; ++e) v[e] += P[e];
+        }
+        for (int e = 0; e < nv; ++e) {
+            int rr = row, cc = col0 + e;
+            if (cc >= g.N) { rr += cc / g.N; cc %= g.N; }
+            float x = v[e] + (g.bias ? g.bias[cc] : 0.f);
+            x = apply_act_rt(x, g.act);
+            if (g.gate) x *= g.gate[(long)map_row(g.gmap, rr) * g.ldg + cc];
+            const long crow = map_row(g.cmap, rr);
+            if (g.R) x += g.R[crow * g.ldr + cc];
+            g.C[crow * g.ldc + cc] = x;
+        }
+    }
+}
+void launch_splitk_reduce(const GemmArgs& g, hipStream_t s) {
+    const long total = (long)g.M * g.N;
+    const long blocks = (total / 4 + 255) / 256;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048)), dim3(256), 0, s, g);
+}
+int gemm_tile_count(const GemmArgs& g, bool f16s) {
+    int bm, bn;
+    if (f16s) { if (gemm_f16s_config(g) == 0) { bm = 128; bn = 128; } else { bm = 64; bn = 64; } }
+    else switch (gemm_config(g)) {
+        case 0: case 4: bm = 128; bn = 128; break;
+        case 1: case 5: bm = 128; bn = 64; break;
+        case 6: bm = 64; bn = 128; break;
+        case 2: case 7: bm = 64; bn = 64; break;
+        default: bm = 32; bn = 128; break;
+    }
+    return ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+}
 }  // namespace artalk
 
 // ---- calibration: register-only v_mfma_f32_32x32x2_f32 loop (no memory traffic) on non-trivial data.  Gives the

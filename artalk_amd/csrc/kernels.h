@@ -41,10 +41,15 @@ struct GemmArgs {
     // amode 1: grouped positional conv window (wav2vec2 pos_conv_embed): row m = (c, t) with
     // t = m % pc_tstride, k = (tap, ci): A[m,k] = X[c*pc_tstride + t + tap - pc_pad, ci] if in [0,pc_T) else 0
     int amode = 0; int pc_T = 0, pc_tstride = 0, pc_pad = 0, pc_cin = 0;
+    // split-K (small-M steps of the AR loop): grid.y = splitk workgroups share one output tile, each writes its raw partial
+    // sums to partial[y][M][N]; launch_splitk_reduce adds them in a fixed order (deterministic) and applies the epilogue.
+    int splitk = 1; float* partial = nullptr;
     int force_cfg = -1;  // >= 0: tile configuration override (tuning/tests)
     int graph_tag = 0;   // 1 for launches inside the captured AR/VAE body (separate kernel symbol, same code)
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);
+void launch_splitk_reduce(const GemmArgs& g, hipStream_t s);   // epilogue pass of a split-K GEMM (g.splitk > 1)
+int gemm_tile_count(const GemmArgs& g, bool f16s);             // output tiles of the configuration launch_gemm[_f16s] would pick
 // fp32-accurate GEMM on the fp16 matrix cores by operand splitting (gemm_f16s.hip)
 void launch_pack_split(const float* w, unsigned int* out, long n, hipStream_t s);
 bool gemm_f16s_eligible(const GemmArgs& g);

@@ -21,6 +21,16 @@ sys.path.insert(0, REPO)
 
 GFLOP_PER_FRAME = 2.159          # algorithmic work with KV cache, BASELINE.md section 3
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
+MODES = {
+    # precision -> (dtype string, dominant kernel symbol prefix in profiles/*pmc*.json, description, peak TF/s of ALGORITHMIC flops, note)
+    "f32": ("f32", "gemm_f32_kernel<128, 128, 2, 2, 16, 0, 0>",
+            "gemm_f32_kernel<128,128,2,2,16,0,0> (v_mfma_f32_32x32x2_f32): every launch of it (wav2vec2 conv/encoder GEMMs, AdaLN table)",
+            PEAK_F32_MFMA_TFLOPS, "fp32 MFMA peak"),
+    "f16x3": ("f32 (operands split into 2 fp16, 3 fp16 MFMA products per fp32 product, fp32 accumulate)", "gemm_f16s_kernel<128, 128, 2, 2, 0, 0>",
+              "gemm_f16s_kernel<128,128,2,2,0,0> (v_mfma_f32_32x32x16_f16 x3 per k-block): every launch of it (wav2vec2 conv/encoder GEMMs, AdaLN table)",
+              PEAK_F16_MFMA_TFLOPS / 3.0, "dense fp16 MFMA peak 2500 TF/s / 3 MFMA products per algorithmic product"),
+}
 
 
 def log(msg):
@@ -59,7 +69,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--config", default="full")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
                     help="GEMM arithmetic: exact fp32 MFMA, or fp16 operand-split MFMA with fp32-class accuracy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=12)
@@ -155,23 +165,22 @@ def main():
     tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tpath):
         for k, v in json.load(open(tpath)).items():
-            if k.startswith("gemm_f32_kernel<128, 128, 2, 2, 16, 0, 0>"):
+            if k.startswith(MODES[args.precision][1]):
                 traffic = round(v["hbm_bytes_per_launch"])
+    dtype, _, kdesc, peak, peak_note = MODES[args.precision]
     roofline = {
-        "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(dom_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-        "kernel": "gemm_f32_kernel<128,128,2,2,16,0,0> (v_mfma_f32_32x32x2_f32): every launch of it (wav2vec2 conv/encoder GEMMs, AdaLN table)",
-        "measured_ceiling": 147.9,   # register-only MFMA loop on this chip, profiles/r01_mfma_peak.log,
+        "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+        "frac": round(dom_tflops / peak, 4), "traffic": traffic, "kernel": kdesc, "peak_note": peak_note,
         "launches": int(prof["dom_launches"]), "avg_launch_ms": round(prof["dom_ms"] / max(prof["dom_launches"], 1), 4),
         "share_of_step_ms": round(prof["dom_ms"], 2),
     }
     result = {
         "metric": "motion frames/sec (25 fps clips) at batch=32 per GPU", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": f"configs[2]: batch={B} synthetic {args.seconds:g} s 16 kHz clips per GPU, {chunks} 4-s chunks, "
                                "hipGraph decode loop, deterministic synthetic weights (489.5 M params)",
-                   "clips_per_gpu": B, "frames_per_clip": frames_per_clip, "mode": "fp32-exact (MFMA f32)",
+                   "clips_per_gpu": B, "frames_per_clip": frames_per_clip, "precision": args.precision,
                    "model_config": args.config},
         "fps_per_clip": round(value / (B * world), 1),
         "algorithmic_tflops": round(value * GFLOP_PER_FRAME / 1e3, 2),
