@@ -165,7 +165,7 @@ def main():
     tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tpath):
         for k, v in json.load(open(tpath)).items():
-            if k.startswith(MODES[args.precision][1]):
+            if isinstance(v, dict) and k.startswith(MODES[args.precision][1]):
                 traffic = round(v["hbm_bytes_per_launch"])
     dtype, _, kdesc, peak, peak_note = MODES[args.precision]
     roofline = {
