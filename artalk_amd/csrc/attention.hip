@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
         for (int d = 0; d < NDT; ++d) {
             f32x4 o = ot[d] * inv;
-            *reinterpret_cast<f32x4*>(op + d * 16 + 4 * g) = o;   // O^T rows 4g..4g+3 of tile d = 4 consecutive d
+            if (a.out_p8) store_p8x4(op, d * 16 + 4 * g, o[0], o[1], o[2], o[3]);   // op is 32-byte aligned (HD % 8 == 0)
+            else *reinterpret_cast<f32x4*>(op + d * 16 + 4 * g) = o;   // O^T rows 4g..4g+3 of tile d = 4 consecutive d
         }
     }
 }

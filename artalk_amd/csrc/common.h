@@ -38,6 +38,22 @@ __device__ __forceinline__ float apply_act_rt(float x, int act) {
     }
 }
 
+// ---- "P8" split format (gemm_f16s.hip): every 8 consecutive elements of a row become 32 bytes [8 x f16 hi][8 x f16 lo],
+// x = hi + lo/2048.  Same pitch as fp32.  store_p8x4 writes elements c..c+3 (c % 4 == 0) of a row whose storage starts at `row`.
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_p8x4(float* row, int c, float x0, float x1, float x2, float x3) {
+    const float x[4] = {x0, x1, x2, x3};
+    f16x4_t h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (_Float16)x[e];
+        l[e] = (_Float16)((x[e] - (float)h[e]) * 2048.0f);
+    }
+    unsigned char* g = reinterpret_cast<unsigned char*>(row) + (c >> 3) * 32 + (c & 4) * 2;
+    *reinterpret_cast<f16x4_t*>(g) = h;
+    *reinterpret_cast<f16x4_t*>(g + 16) = l;
+}
+
 // full-wave (64 lanes) butterfly reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -87,6 +87,7 @@ struct artalk_model {
     struct PackRange { const float* base; int64_t n; unsigned int* packed; };
     std::vector<PackRange> wranges;   // every weight allocation and its packed f16x3 copy (built at finalize)
     int precision = 0;                // 0: fp32 MFMA everywhere, 1: f16x3 split GEMMs (heads stay fp32)
+    bool sticky_error = false;        // set by internal consistency checks inside the launch sequence; reported by artalk_infer
     // derived sizes
     int n_conv = 0; int conv_T[8]{}; int conv_S[8]{};   // valid frames / padded row stride per conv layer output
     int Tw = 0, Ts = 0;                                 // 199, 200
@@ -354,10 +355,13 @@ void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
             if (S > 1) { g.splitk = S; g.partial = m->ws.splitk; }
         }
     }
-    const bool dominant = !m->in_body && g.M > 0 && (split ? gemm_f16s_config(g) == 0 : gemm_config(g) == 4);
+    const bool dominant = !m->in_body && g.M > 0 &&
+                          (split ? (g.a_packed ? gemm_p8_eligible(g) : gemm_f16s_config(g) == 0) : gemm_config(g) == 4);
     size_t i0 = 0, i1 = 0;
     if (m->profiling && dominant) next_event(m, s, &i0);
-    if (split) launch_gemm_f16s(g, s); else launch_gemm(g, s);
+    if (g.a_packed && !split) { m->err = "internal: P8 activation handed to an fp32 GEMM"; m->sticky_error = true; return; }
+    const bool dma = split && g.splitk == 1 && gemm_p8_eligible(g);
+    if (dma) launch_gemm_p8(g, s); else if (split) launch_gemm_f16s(g, s); else launch_gemm(g, s);
     if (g.splitk > 1) launch_splitk_reduce(g, s);
     if (m->profiling && dominant) {
         next_event(m, s, &i1);
@@ -365,18 +369,20 @@ void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
     }
 }
 
+enum { LF_EXACT = 1, LF_A_P8 = 2, LF_C_P8 = 4 };   // linear() flags: decision-critical (fp32 path) / A is in P8 / write C in P8
 // plain y = act(x W^T + b) [+ R]
 void linear(artalk_model* m, const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N, int K,
-            int act, const float* R, hipStream_t s, int exact = 0) {
+            int act, const float* R, hipStream_t s, int flags = 0) {
     GemmArgs g;
-    g.exact = exact;
+    g.exact = flags & LF_EXACT; g.a_packed = (flags & LF_A_P8) ? 1 : 0; g.c_p8 = (flags & LF_C_P8) ? 1 : 0;
     g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act;
     g.R = R; g.ldr = ldc;
     gemm(m, g, s);
 }
 
-void layernorm(const float* X, float* Y, const float* w, const float* b, int M, int D, float eps, int act, hipStream_t s) {
+void layernorm(const float* X, float* Y, const float* w, const float* b, int M, int D, float eps, int act, hipStream_t s, int out_p8 = 0) {
     LnArgs a;
+    a.out_p8 = out_p8;
     a.X = X; a.ldx = D; a.Y = Y; a.ldy = D; a.w = w; a.b = b; a.M = M; a.D = D; a.eps = eps; a.act = act;
     launch_layernorm(a, s);
 }
@@ -387,24 +393,29 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     const artalk_config& c = m->cfg;
     Workspace& w = m->ws;
     const int CD = c.w2v_conv_dim, Hs = c.w2v_hidden;
+    // f16x3 mode: every activation whose only consumer is a GEMM is written by its producer directly in the P8 split
+    // format (same bytes), so the big GEMMs can stage both operands with LDS-DMA (gemm_p8_kernel).
+    const int p8 = m->precision == 1 ? 1 : 0;
+    const int AP = p8 ? LF_A_P8 : 0;
     launch_audio_normalize(audio, w.src_off + c0, w.xnorm, n, kSamplesPerChunk, s);
     launch_conv0(w.xnorm, kSamplesPerChunk, m->conv0_w, m->conv_b[0], m->conv_lnw[0], m->conv_lnb[0], w.convA, n, m->conv_T[0],
-                 m->conv_S[0], s);
+                 m->conv_S[0], s, p8);
     float* src = w.convA; float* dst = w.convB;
     for (int i = 1; i < c.w2v_n_conv; ++i) {
         // stride-2 conv as a GEMM: output row r reads input rows 2r..2r+k-1 (contiguous K = k*512 floats)
         const int M = n * m->conv_S[i];
         linear(m, src, (long)c.w2v_conv_stride[i] * CD, m->conv_w[i], m->conv_b[i], dst, CD, M, CD, c.w2v_conv_kernel[i] * CD,
-               ACT_NONE, nullptr, s);
-        layernorm(dst, dst, m->conv_lnw[i], m->conv_lnb[i], M, CD, 1e-5f, ACT_GELU_ERF, s);
+               ACT_NONE, nullptr, s, AP);
+        // the last conv output feeds a LayerNorm (feature projection), not a GEMM: it stays fp32
+        layernorm(dst, dst, m->conv_lnw[i], m->conv_lnb[i], M, CD, 1e-5f, ACT_GELU_ERF, s, (p8 && i + 1 < c.w2v_n_conv) ? 1 : 0);
         std::swap(src, dst);
     }
     stage_mark(m, s, PB_CONV);
     const int M = n * m->Ts;
     // feature projection (hf:429-434)
-    layernorm(src, dst, m->fp_lnw, m->fp_lnb, M, CD, c.w2v_ln_eps, ACT_NONE, s);
-    linear(m, dst, CD, m->fp_w, m->fp_b, w.h0, Hs, M, Hs, CD, ACT_NONE, nullptr, s);
-    // positional conv embedding (hf:360-368): h1 = h0 + gelu(groupconv(h0) + b)
+    layernorm(src, dst, m->fp_lnw, m->fp_lnb, M, CD, c.w2v_ln_eps, ACT_NONE, s, p8);
+    linear(m, dst, CD, m->fp_w, m->fp_b, w.h0, Hs, M, Hs, CD, ACT_NONE, nullptr, s, AP);
+    // positional conv embedding (hf:360-368): h1 = h0 + gelu(groupconv(h0) + b)   (fp32 kernel: gathers the padded window)
     {
         const int cg = Hs / c.w2v_pos_groups;
         GemmArgs g;
@@ -418,24 +429,25 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     const int nh = c.w2v_heads, hd = Hs / nh;
     for (int i = 0; i < c.w2v_layers; ++i) {
         const W2VLayer& L = m->w2v[i];
-        layernorm(h, w.xln, L.ln1w, L.ln1b, M, Hs, c.w2v_ln_eps, ACT_NONE, s);
-        linear(m, w.xln, Hs, L.qkv_w, L.qkv_b, w.qkv, 3 * Hs, M, 3 * Hs, Hs, ACT_NONE, nullptr, s);
+        layernorm(h, w.xln, L.ln1w, L.ln1b, M, Hs, c.w2v_ln_eps, ACT_NONE, s, p8);
+        linear(m, w.xln, Hs, L.qkv_w, L.qkv_b, w.qkv, 3 * Hs, M, 3 * Hs, Hs, ACT_NONE, nullptr, s, AP);
         AttnArgs a;
         a.Q = w.qkv; a.K = w.qkv + Hs; a.V = w.qkv + 2 * Hs;
         a.ldq = a.ldk = a.ldv = 3 * Hs; a.q_bstride = a.k_bstride = a.v_bstride = (long)m->Ts * 3 * Hs;
         a.O = w.att; a.ldo = Hs; a.o_bstride = (long)m->Ts * Hs;
         a.B = n; a.H = nh; a.HD = hd; a.Lq = m->Tw; a.Lk = m->Tw; a.scale = 1.0f / std::sqrt((float)hd);
+        a.out_p8 = p8;
         launch_attention(a, s);
-        linear(m, w.att, Hs, L.out_w, L.out_b, h, Hs, M, Hs, Hs, ACT_NONE, h, s);
-        layernorm(h, w.xln, L.ln2w, L.ln2b, M, Hs, c.w2v_ln_eps, ACT_NONE, s);
-        linear(m, w.xln, Hs, L.ff1_w, L.ff1_b, w.ffn, c.w2v_ffn, M, c.w2v_ffn, Hs, ACT_GELU_ERF, nullptr, s);
-        linear(m, w.ffn, c.w2v_ffn, L.ff2_w, L.ff2_b, h, Hs, M, Hs, c.w2v_ffn, ACT_NONE, h, s);
+        linear(m, w.att, Hs, L.out_w, L.out_b, h, Hs, M, Hs, Hs, ACT_NONE, h, s, AP);
+        layernorm(h, w.xln, L.ln2w, L.ln2b, M, Hs, c.w2v_ln_eps, ACT_NONE, s, p8);
+        linear(m, w.xln, Hs, L.ff1_w, L.ff1_b, w.ffn, c.w2v_ffn, M, c.w2v_ffn, Hs, ACT_GELU_ERF, nullptr, s, AP | (p8 ? LF_C_P8 : 0));
+        linear(m, w.ffn, c.w2v_ffn, L.ff2_w, L.ff2_b, h, Hs, M, Hs, c.w2v_ffn, ACT_NONE, h, s, AP);
     }
     layernorm(h, w.xln, m->enc_lnw, m->enc_lnb, M, Hs, c.w2v_ln_eps, ACT_NONE, s);
     if (out_w2v)
         (void)hipMemcpy2DAsync(out_w2v + (long)c0 * m->Tw * Hs, (size_t)m->Tw * Hs * 4, w.xln, (size_t)m->Ts * Hs * 4,
                                (size_t)m->Tw * Hs * 4, n, hipMemcpyDeviceToDevice, s);
-    launch_pool_silu(w.xln, m->Ts, m->Tw, w.silu_cond + (long)c0 * kNTok * kCond, n, m->pn, c.n_levels, kCond, s);
+    launch_pool_silu(w.xln, m->Ts, m->Tw, w.silu_cond + (long)c0 * kNTok * kCond, n, m->pn, c.n_levels, kCond, s, p8);
     stage_mark(m, s, PB_ENC);
 }
 
@@ -497,7 +509,7 @@ void run_reencode(artalk_model* m, int B, hipStream_t s) {
     const int H = c.vae_hidden, T = 100;
     linear(m, w.enc_in, 128, m->enc.in_w, m->enc.in_b, w.vh, H, B * T, H, 128, ACT_LEAKY02, nullptr, s);
     run_vae_stack(m, m->enc, B, T, 0, s);
-    linear(m, w.vh, H, m->enc.out_w, m->enc.out_b, w.enc_out, c.code_dim, B * T, c.code_dim, H, ACT_NONE, nullptr, s, /*exact=*/1);
+    linear(m, w.vh, H, m->enc.out_w, m->enc.out_b, w.enc_out, c.code_dim, B * T, c.code_dim, H, ACT_NONE, nullptr, s, LF_EXACT);
     launch_bsq_history(w.enc_out, w.hist_bits, w.prev_fdec, w.msfeat, B, s);
     launch_vq_embed(w.msfeat, kNTok - 1, m->vq_w, m->vq_b, m->prev_lvl_pos + kE, w.prev_in, kNTok, 1, w.style_cond,
                     m->prev_lvl_pos, B, s);
@@ -561,7 +573,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
         nh.X = w.x; nh.ldx = kE; nh.Y = w.xmod; nh.ldy = kE; nh.scale = hada; nh.shift = hada + kE; nh.ldm = ldada; nh.mmap = amap;
         nh.M = M; nh.D = kE; nh.eps = 1e-6f;
         launch_layernorm(nh, s);
-        linear(m, w.xmod, kE, m->logits_w, m->logits_b, w.logits, 2 * c.code_dim, M, 2 * c.code_dim, kE, ACT_NONE, nullptr, s, /*exact=*/1);
+        linear(m, w.xmod, kE, m->logits_w, m->logits_b, w.logits, 2 * c.code_dim, M, 2 * c.code_dim, kE, ACT_NONE, nullptr, s, LF_EXACT);
         launch_ar_bits_next(w.logits, w.bits, w.fhat, w.nextfeat, B, p, s);
         if (p + 1 < c.n_levels)
             launch_vq_embed(w.nextfeat, m->pn[p + 1], m->vq_w, m->vq_b, m->lvl_pos + (long)m->off[p + 1] * kE, w.x, m->pn[p + 1], 0,
@@ -878,7 +890,7 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
         const int Bn = Bj[j];
         // AdaLN table of this chunk index for all blocks + head: SiLU(cond) @ [W_0;...;W_11;W_head]^T
         linear(m, w.silu_cond + (long)base[j] * kNTok * kCond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, Bn * kNTok, m->ada_n, kCond,
-               ACT_NONE, nullptr, s);
+               ACT_NONE, nullptr, s, m->precision == 1 ? LF_A_P8 : 0);
         stage_mark(m, s, PB_ADA);
         if (graphs) {
             auto it = m->graphs.find(Bn);
@@ -911,6 +923,7 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
     }
     stage_mark(m, s, PB_OTHER);
     HIPCHK(m, hipGetLastError());
+    if (m->sticky_error) { m->sticky_error = false; return ARTALK_ESTATE; }
     return ARTALK_OK;
 }
 
@@ -1003,7 +1016,13 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
     GemmArgs g;
     g.A = (const float*)A; g.a_packed = a_packed; g.lda = lda; g.W = nullptr; g.Wp = (const unsigned int*)Wp; g.ldw = K; g.bias = bias;
     g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act; g.force_cfg = force_cfg;
-    launch_gemm_f16s(g, (hipStream_t)stream);
+    if (force_cfg >= 2) {   // LDS-DMA pipelined kernel (needs both operands in P8); 3 / 5 select the pipeline depth, 2 = default
+        if (!a_packed) return ARTALK_EINVAL;
+        g.force_cfg = force_cfg == 2 ? -1 : force_cfg;
+        launch_gemm_p8(g, (hipStream_t)stream);
+    } else {
+        launch_gemm_f16s(g, (hipStream_t)stream);
+    }
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }
 
@@ -1012,7 +1031,7 @@ int artalk_op_layernorm(const float* X, float* Y, const float* w, const float* b
     if (!X || !Y || (D != 128 && D != 512 && D != 768 && D != 1024)) return ARTALK_EINVAL;
     LnArgs a;
     a.X = X; a.ldx = D; a.Y = Y; a.ldy = D; a.w = w; a.b = b; a.scale = scale; a.shift = shift; a.ldm = D; a.M = M; a.D = D;
-    a.eps = eps; a.act = act;
+    a.eps = eps; a.act = act & 0xff; a.out_p8 = (act & 0x100) ? 1 : 0;   // act | 0x100: write Y in the P8 split format
     launch_layernorm(a, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }

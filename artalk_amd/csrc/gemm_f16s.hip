@@ -12,8 +12,8 @@
 // outputs or weights); operands are never denormal-flushed (residuals are rescaled).
 //
 // Memory layout is unchanged: activations stay fp32 in HBM and are split while they are staged into LDS; weights are
-// pre-split once at load into a packed (hi | lo << 16) word per element, so a packed matrix has the same size, the
-// same indexing and the same 16-byte loads as the fp32 one.  LDS rows hold the hi plane (BK halves) followed by the
+// pre-split once at load into the "P8" format (every 8 elements -> 16 bytes of hi halves + 16 bytes of lo halves), so
+// a packed matrix has the same size, pitch and 16-byte loads as the fp32 one and a 16-byte chunk is an MFMA fragment.  LDS rows hold the hi plane (BK halves) followed by the
 // lo plane, padded to 144 bytes (conflict-free ds_read_b128 for the 32x32x16 operand map: lane (r,h) holds k = 8h..8h+7).
 #include "common.h"
 
@@ -36,25 +36,28 @@ __device__ __forceinline__ void split_f32x4(const f32x4 x, u32x2& hi, u32x2& lo)
     hi = __builtin_bit_cast(u32x2, h);
     lo = __builtin_bit_cast(u32x2, l);
 }
-__device__ __forceinline__ void unpack_x4(const u32x4 p, u32x2& hi, u32x2& lo) {
-    hi[0] = __builtin_amdgcn_perm(p[1], p[0], 0x05040100u);   // low halves of p0,p1
-    hi[1] = __builtin_amdgcn_perm(p[3], p[2], 0x05040100u);
-    lo[0] = __builtin_amdgcn_perm(p[1], p[0], 0x07060302u);   // high halves
-    lo[1] = __builtin_amdgcn_perm(p[3], p[2], 0x07060302u);
-}
+// Register-staged kernel: thread (row, chunk c = 0..7) of a K tile of 32 handles one 16-byte chunk.  For an fp32 operand the
+// chunk is elements 4c..4c+3 (split here: 8 B hi + 8 B lo); for a P8 operand chunk c is already a fragment: group c>>1,
+// hi (c even) or lo (c odd), copied as is.  LDS row: [hi plane: 4 groups x 16 B][lo plane: 4 groups x 16 B] + 16 B pad.
+__device__ __forceinline__ int p8_lds_offset(int c) { return (c & 1) * 64 + (c >> 1) * 16; }
 
-// fp32 -> packed (f16 hi | f16 lo << 16), elementwise
+// fp32 -> "P8" split format, 8 elements per thread: each group of 8 consecutive elements becomes 32 bytes
+// [8 x f16 hi][8 x f16 lo] (same size as the 8 floats it replaces, so a P8 matrix keeps the fp32 matrix's pitch and
+// indexing).  A 16-byte chunk of a P8 row is therefore directly an MFMA operand fragment (k = 8h .. 8h+7).
 __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, unsigned int* __restrict__ out, long n) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const float x = w[i];
-        const _Float16 h = (_Float16)x;
-        const _Float16 l = (_Float16)((x - (float)h) * kLoScale);
-        out[i] = (unsigned int)__builtin_bit_cast(unsigned short, h) | ((unsigned int)__builtin_bit_cast(unsigned short, l) << 16);
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long)gridDim.x * 2048) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(w + i), b = *reinterpret_cast<const f32x4*>(w + i + 4);
+        u32x2 h0, l0, h1, l1;
+        split_f32x4(a, h0, l0);
+        split_f32x4(b, h1, l1);
+        u32x4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
+        *reinterpret_cast<u32x4*>(out + i) = hi;
+        *reinterpret_cast<u32x4*>(out + i + 4) = lo;
     }
 }
 void launch_pack_split(const float* w, unsigned int* out, long n, hipStream_t s) {
     if (n <= 0) return;
-    const long blocks = (n + 255) / 256;
+    const long blocks = (n / 8 + 255) / 256;   // n % 8 == 0 (every packed tensor has an inner dimension that is a multiple of 32)
     hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, w, out, n);
 }
 
@@ -111,19 +114,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            u32x2 hi, lo;
-            if (APK) unpack_x4(ra[i], hi, lo); else split_f32x4(__builtin_bit_cast(f32x4, ra[i]), hi, lo);
-            unsigned char* p = As + (buf * BM + lrow + i * 32) * ROWB + lc4 * 2;
-            *reinterpret_cast<u32x2*>(p) = hi;
-            *reinterpret_cast<u32x2*>(p + 64) = lo;
+            unsigned char* p = As + (buf * BM + lrow + i * 32) * ROWB;
+            if (APK) {
+                *reinterpret_cast<u32x4*>(p + p8_lds_offset(tid & 7)) = ra[i];
+            } else {
+                u32x2 hi, lo;
+                split_f32x4(__builtin_bit_cast(f32x4, ra[i]), hi, lo);
+                *reinterpret_cast<u32x2*>(p + lc4 * 2) = hi;
+                *reinterpret_cast<u32x2*>(p + lc4 * 2 + 64) = lo;
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
-            u32x2 hi, lo;
-            unpack_x4(rb[i], hi, lo);
-            unsigned char* p = Bs + (buf * BN + lrow + i * 32) * ROWB + lc4 * 2;
-            *reinterpret_cast<u32x2*>(p) = hi;
-            *reinterpret_cast<u32x2*>(p + 64) = lo;
+            *reinterpret_cast<u32x4*>(Bs + (buf * BN + lrow + i * 32) * ROWB + p8_lds_offset(tid & 7)) = rb[i];
         }
     };
 
@@ -209,11 +212,198 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
                     if (g.gate) v *= g.gate[(long)map_row(g.gmap, row) * g.ldg + col];
                     const long crow = map_row(g.cmap, row);
                     if (R) v += R[crow * g.ldr + col];
+                    if (g.c_p8) {   // hand the result to the next split GEMM already in P8
+                        _Float16* o = reinterpret_cast<_Float16*>(C + crow * g.ldc + (col & ~7));
+                        const _Float16 hh = (_Float16)v;
+                        o[col & 7] = hh;
+                        o[8 + (col & 7)] = (_Float16)((v - (float)hh) * kLoScale);
+                    } else {
+                        C[crow * g.ldc + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA pipeline variant for the large GEMMs: BOTH operands already in P8 (A written in P8 by its producer kernel), so
+// staging is a pure byte copy and goes global -> LDS directly (global_load_lds_dwordx4: no staging registers), STAGES-1
+// K tiles in flight behind counted vmcnt waits and ONE raw s_barrier per K step.  The register-staged kernel above has a
+// single K tile of prefetch and is load-latency bound; here 3 tiles (96 KiB) stay in flight per CU.
+//   tile 128x128, BK = 32, 8 waves (2 x 4, each 64 x 32: 2 m-tiles x 1 n-tile, main + cross accumulators = 64 regs)
+//   LDS stage: A 128 rows x 128 B, then W 128 rows x 128 B, rows unpadded (a DMA wave-instruction writes 1 KiB = 8 rows);
+//   16-byte chunk c of row r lives at physical chunk c ^ ((r >> 1) & 7): the XOR is applied to the per-lane SOURCE address
+//   of the DMA and again on the fragment read (same involution), which makes the ds_read_b128 fragment reads conflict-free.
+template <int STAGES>
+__global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    int tm, tn;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GM = 4;
+        const int width = GM * tiles_n;
+        const int group = idx / width, first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        const int in_g = idx - group * width;
+        tn = in_g / gsz;
+        tm = first_m + (in_g - tn * gsz);
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- DMA addressing: per stage each wave issues 2 A pieces and 2 W pieces of 1 KiB (8 rows x 128 B) ----
+    const int prow = lane >> 3, pchunk = lane & 7;            // row within the piece, physical chunk
+    const unsigned char* asrc[2];
+    const unsigned char* wsrc[2];
+    int lds_piece[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int ra = (wave * 2 + q) * 8 + prow;             // tile row 0..127
+        const int ca = pchunk ^ ((ra >> 1) & 7);              // logical chunk fetched into physical slot pchunk
+        const int gm = min(m0 + ra, g.M - 1), gn = min(n0 + ra, g.N - 1);   // clamp: rows >= M/N are never stored
+        asrc[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda) * 4 + ca * 16;
+        wsrc[q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw) * 4 + ca * 16;
+        lds_piece[q] = (wave * 2 + q) * 1024;
+        lds_piece[2 + q] = BM * 128 + (wave * 2 + q) * 1024;
+    }
+    auto issue = [&](int kt, int buf) {
+        unsigned char* base = smem_p8 + buf * STAGE_BYTES;
+        const long koff = (long)kt * (BK * 4);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[q] + koff),
+                                             (__attribute__((address_space(3))) void*)(base + lds_piece[q]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + koff),
+                                             (__attribute__((address_space(3))) void*)(base + lds_piece[2 + q]), 16, 0, 0);
+        }
+    };
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+    int a_row_off[2], a_key[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + i * 32 + r;
+        a_row_off[i] = row * 128;
+        a_key[i] = (row >> 1) & 7;
+    }
+    const int wrow = wn * 32 + r;
+    const int w_row_off = BM * 128 + wrow * 128, w_key = (wrow >> 1) & 7;
+
+    f32x16 accm[2], accx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { accm[i][e] = 0.f; accx[i][e] = 0.f; }
+
+    const int nk = g.K / BK;
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st < nk) issue(st, st);
+
+    // Fragment registers are one half-step ahead of the MFMAs, so LDS-read latency and the stage hand-over (vmcnt wait +
+    // barrier) sit under matrix work instead of in front of it:
+    //   iteration kt:  read kb=1 frags of stage kt | MFMA kb=0 | wait stage kt+1, barrier, DMA stage kt+S-1 |
+    //                  read kb=0 frags of stage kt+1 | MFMA kb=1
+    auto wait_stage = [&](int st) {   // stage st landed for THIS wave: at most `younger` later stages (4 DMA instr each) in flight
+        const int younger = min(STAGES - 3, nk - 1 - st);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto read_frags = [&](const unsigned char* base, int kb, f16x8 (&ah)[2], f16x8 (&al)[2], f16x8& bh, f16x8& bl) {
+        const int c = (kb * 2 + h) * 2;               // logical chunk of the hi fragment; lo = c + 1
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8*>(base + a_row_off[i] + ((c ^ a_key[i]) << 4));
+            al[i] = *reinterpret_cast<const f16x8*>(base + a_row_off[i] + (((c + 1) ^ a_key[i]) << 4));
+        }
+        bh = *reinterpret_cast<const f16x8*>(base + w_row_off + ((c ^ w_key) << 4));
+        bl = *reinterpret_cast<const f16x8*>(base + w_row_off + (((c + 1) ^ w_key) << 4));
+    };
+    auto mfma6 = [&](const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8& bh, const f16x8& bl) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, accm[i], 0, 0, 0);
+            accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, accx[i], 0, 0, 0);
+            accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, accx[i], 0, 0, 0);
+        }
+    };
+
+    f16x8 ah0[2], al0[2], bh0, bl0, ah1[2], al1[2], bh1, bl1;
+    {   // stage 0: the DMA prologue left stages 1..STAGES-2 younger than it
+        const int younger = min(STAGES - 2, nk - 1);
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(smem_p8, 0, ah0, al0, bh0, bl0);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned char* base = smem_p8 + (kt % STAGES) * STAGE_BYTES;
+        read_frags(base, 1, ah1, al1, bh1, bl1);
+        mfma6(ah0, al0, bh0, bl0);
+        if (kt + 1 < nk) {
+            wait_stage(kt + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of stage kt are back before anyone may overwrite it
+            __builtin_amdgcn_s_barrier();                          // stage kt+1 visible to all; all waves are done with stage kt-1
+            if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);   // reuses the buffer of stage kt-1
+            read_frags(smem_p8 + ((kt + 1) % STAGES) * STAGE_BYTES, 0, ah0, al0, bh0, bl0);
+        }
+        mfma6(ah1, al1, bh1, bl1);
+    }
+
+    const float* __restrict__ bias = g.bias;
+    float* __restrict__ C = g.C;
+    const float* R = g.R;
+    const int col = n0 + wn * 32 + r;
+    const bool cok = col < g.N;
+    const float bv = (bias && cok) ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (row < g.M && cok) {
+                float v = (accm[i][e] + accx[i][e] * kLoInv) + bv;
+                v = apply_act_rt(v, g.act);
+                if (g.gate) v *= g.gate[(long)map_row(g.gmap, row) * g.ldg + col];
+                const long crow = map_row(g.cmap, row);
+                if (R) v += R[crow * g.ldr + col];
+                if (g.c_p8) {   // hand the result to the next split GEMM already in P8 (element col of the row -> hi/lo planes of its group)
+                    _Float16* o = reinterpret_cast<_Float16*>(C + crow * g.ldc + (col & ~7));
+                    const _Float16 hh = (_Float16)v;
+                    o[col & 7] = hh;
+                    o[8 + (col & 7)] = (_Float16)((v - (float)hh) * kLoScale);
+                } else {
                     C[crow * g.ldc + col] = v;
                 }
             }
         }
     }
+}
+
+void launch_gemm_p8(const GemmArgs& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return;
+    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    switch (g.force_cfg) {   // tuning: pipeline depth (default 4 stages = 128 KiB of LDS, 2 K tiles in flight + 1 being read ahead)
+        case 3: hipLaunchKernelGGL(gemm_p8_kernel<3>, dim3(tiles), dim3(512), 3 * 256 * 128, s, g); break;
+        case 5: hipLaunchKernelGGL(gemm_p8_kernel<5>, dim3(tiles), dim3(512), 5 * 256 * 128, s, g); break;
+        default: hipLaunchKernelGGL(gemm_p8_kernel<4>, dim3(tiles), dim3(512), 4 * 256 * 128, s, g); break;
+    }
+}
+bool gemm_p8_eligible(const GemmArgs& g) {
+    return g.Wp != nullptr && g.a_packed && g.amode == 0 && g.batch == 1 && g.splitk == 1 && g.K % 32 == 0 && (g.lda % 8) == 0 &&
+           (long)((g.M + 127) / 128) * ((g.N + 127) / 128) >= 384;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -232,8 +422,10 @@ static void launch_f16s_cfg(const GemmArgs& g, hipStream_t s) {
 // 0: 128x128 (dominant kernel of the split mode), 1: 64x64
 int gemm_f16s_config(const GemmArgs& g) {
     if (g.force_cfg >= 0) return g.force_cfg;
+    // 64x64 tiles (4-5 workgroups/CU) beat 128x128 (2/CU) until the grid is several waves deep: M=3200,N=3072,K=768 runs at
+    // 210 vs 135 TF/s (profiles/r01_gemm_f16s_bench.log)
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    return t128 >= 512 ? 0 : 1;
+    return t128 >= 1024 ? 0 : 1;
 }
 
 bool gemm_f16s_eligible(const GemmArgs& g) {

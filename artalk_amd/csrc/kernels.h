@@ -28,6 +28,7 @@ struct GemmArgs {
     const float* A = nullptr; long lda = 0;
     const float* W = nullptr; long ldw = 0;
     const unsigned int* Wp = nullptr;   // optional packed (f16 hi | f16 lo << 16) copy of W, same ld: f16x3 split path
+    int c_p8 = 0;                        // 1: write C in the P8 split format (the consumer is a split GEMM), gemm_p8_kernel only
     int a_packed = 0;                    // 1: A already holds packed split words (written by a producer kernel), f16x3 path only
     int exact = 0;                       // 1: decision-critical GEMM (logit / code heads), always on the fp32 MFMA path
     const float* bias = nullptr;
@@ -55,6 +56,8 @@ void launch_pack_split(const float* w, unsigned int* out, long n, hipStream_t s)
 bool gemm_f16s_eligible(const GemmArgs& g);
 int gemm_f16s_config(const GemmArgs& g);     // 0: 128x128 (dominant kernel of the split mode), 1: 64x64
 void launch_gemm_f16s(const GemmArgs& g, hipStream_t s);
+bool gemm_p8_eligible(const GemmArgs& g);      // both operands in P8 and a large grid: LDS-DMA pipelined kernel
+void launch_gemm_p8(const GemmArgs& g, hipStream_t s);
 int gemm_config(const GemmArgs& g);   // 4: 128x128 BK16 (dominant kernel), 2: 64x64, 1: 128x64, 3: 32x128; 0,5,6,7 tuning variants
 // Average kernel time helper for benches: FLOPs of one launch
 static inline double gemm_flops(const GemmArgs& g) { return 2.0 * g.M * (double)g.N * g.K * g.batch; }
@@ -68,6 +71,7 @@ struct LnArgs {
     const float* scale = nullptr; const float* shift = nullptr;  // AdaLN modulation (nullable), row stride ldm
     long ldm = 0; RowMap mmap = {INT_MAX, 0, 0};
     int M = 0, D = 0; float eps = 1e-5f; int act = ACT_NONE;
+    int out_p8 = 0;   // 1: write Y in the P8 split format (consumer is a split GEMM); same row pitch as fp32
 };
 void launch_layernorm(const LnArgs& a, hipStream_t s);
 
@@ -81,6 +85,7 @@ struct AttnArgs {
     float scale = 1.f;
     int l2norm = 0; const float* qscale = nullptr;   // AR: q,k L2-normalised, q *= qscale[h]
     int split_q = 0, split_k = 0;                    // queries < split_q see keys < split_k only (VAE mask)
+    int out_p8 = 0;                                  // 1: write O in the P8 split format
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -89,10 +94,10 @@ void launch_attention(const AttnArgs& a, hipStream_t s);
 void launch_audio_normalize(const float* audio, const long* src_off, float* xnorm, int n_chunks, int n, hipStream_t s);
 // conv0 (Cin=1,k=10,s=5) + bias + LN(512, affine) + GELU(erf): xnorm [C, n] -> Y rows c*row_stride + t, t < T
 void launch_conv0(const float* xnorm, int n, const float* w /*[512,10]*/, const float* bias, const float* lnw,
-                  const float* lnb, float* Y, int n_chunks, int T, int row_stride, hipStream_t s);
+                  const float* lnb, float* Y, int n_chunks, int T, int row_stride, hipStream_t s, int out_p8 = 0);
 // multi-scale adaptive average pooling 199 -> {1,5,25,50,100} followed by SiLU: X rows c*x_tstride + t -> Y rows c*181 + tok
 void launch_pool_silu(const float* X, int x_tstride, int T, float* Y, int n_chunks, const int* patch_nums, int n_lvls,
-                      int D, hipStream_t s);
+                      int D, hipStream_t s, int out_p8 = 0);
 
 // ---- AR / VAE glue ----
 // level p: logits [B*pn, 64] -> bits[b, off..off+pn, 32]; fhat[b] += up(h_p); nextfeat[b, :pn[p+1], 32] = area(fhat) (p < 4)

@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
             if (sc) t = t * (sc[c + e] + 1.0f) + sh[c + e];
             o[e] = apply_act_rt(t, a.act);
         }
-        if (VW == 4) {
+        if (VW == 4 && a.out_p8) {
+            store_p8x4(y, c, o[0], o[1], o[2], o[3]);
+        } else if (VW == 4) {
             f32x4 t = {o[0], o[1], o[2], o[3]};
             *reinterpret_cast<f32x4*>(y + c) = t;
         } else {

@@ -121,7 +121,7 @@ int artalk_op_gemm_f16s(const float* A, int64_t lda, const float* W, const float
 int artalk_op_pack_split(const float* in, void* out_u32, int64_t n, void* stream);
 int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const void* Wp, const float* bias, float* C, int M, int N,
                                int K, int act, int force_cfg, void* stream);
-/* y = LN(x)[*w+b][*(1+scale)+shift][act], D in {128,512,768,1024} */
+/* y = LN(x)[*w+b][*(1+scale)+shift][act], D in {128,512,768,1024}; act | 0x100 writes y in the P8 split format */
 int artalk_op_layernorm(const float* X, float* Y, const float* w, const float* b, const float* scale, const float* shift,
                         int M, int D, float eps, int act, void* stream);
 /* Q,K,V,O: [B][L][H*HD] contiguous; l2norm!=0 -> q,k normalised, q *= qscale[h]; split: queries<split see keys<split */

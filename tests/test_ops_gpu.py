@@ -92,6 +92,33 @@ def test_gemm_f16x3_split_is_fp32_accurate(M, N, K, cfg):
     assert err < 1.5e-6 and err < 4 * err32 + 2e-7, (err, err32)
 
 
+def test_gemm_p8_dma_pipeline_and_producers():
+    """The LDS-DMA pipelined split GEMM (both operands in the P8 split format) against float64, with A produced in P8 by
+    the LayerNorm kernel's out_p8 mode (what the wav2vec2 stage does) and by the pack kernel."""
+    capi, L = _lib()
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 8192 + 77, 1024, 1024
+    X = torch.randn(M, K, generator=g) * 2 + 0.1
+    lw, lb = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    A = F.layer_norm(X.double(), (K,), lw.double(), lb.double(), 1e-5)
+    ref = A @ W.double().t() + bias.double()
+    dX, dlw, dlb, dW, db = _dev(X), _dev(lw), _dev(lb), _dev(W), _dev(bias)
+    Ap = torch.empty(M, K, dtype=torch.int32, device="cuda")     # P8 has the fp32 pitch
+    Wp = torch.empty(N, K, dtype=torch.int32, device="cuda")
+    assert L.artalk_op_pack_split(_p(dW), _p(Wp), N * K, None) == 0
+    # LayerNorm -> P8 (flag in the high bits of `act`: see artalk_op_layernorm)
+    assert L.artalk_op_layernorm(_p(dX), _p(Ap), _p(dlw), _p(dlb), None, None, M, K, 1e-5, 0x100, None) == 0
+    out = torch.full((M, N), float("nan"), device="cuda")
+    for cfg in (2, 0, 1):       # DMA pipeline, register-staged 128x128 and 64x64, all fed with the P8 activation
+        out.fill_(float("nan"))
+        assert L.artalk_op_gemm_f16s_packed(_p(Ap), 1, K, _p(Wp), _p(db), _p(out), M, N, K, 0, cfg, None) == 0
+        torch.cuda.synchronize()
+        err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1.5e-6, (cfg, err)
+
+
 def test_gemm_exact_integers():
     """A = I-like and asymmetric small integers: the MFMA lane maps (no row/col swap) are exact in fp32."""
     capi, L = _lib()

@@ -9,15 +9,22 @@ p = lambda t: C.c_void_p(t.data_ptr())
 SHAPES = [("w2v qkv", 19200, 3072, 1024), ("w2v out", 19200, 1024, 1024), ("w2v ff1", 19200, 4096, 1024), ("w2v ff2", 19200, 1024, 4096),
           ("conv1", 614400, 512, 1536), ("ada", 5792, 56832, 1024), ("ar ffn1 p4", 3200, 3072, 768), ("ar ffn2 p4", 3200, 768, 3072),
           ("ar qkv p2", 800, 2304, 768), ("ar ffn2 p2", 800, 768, 3072)]
-variants = [(0, 0), (0, 1), (1, 0), (1, 1)]
+variants = [(0, 1), (3, 1), (2, 1), (5, 1)]   # (tile cfg, A packed): cfg 2 = LDS-DMA pipelined kernel
+only = os.environ.get("GEMM_ONLY")
+if only:
+    SHAPES = [x for x in SHAPES if x[0] in only.split(",")]
+if os.environ.get("GEMM_VARIANTS"):
+    variants = [tuple(int(v) for v in x.split(":")) for x in os.environ["GEMM_VARIANTS"].split(",")]
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for name, M, N, K in SHAPES:
     A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.03; b = torch.randn(N, device="cuda")
     Ap = torch.empty(M, K, dtype=torch.int32, device="cuda"); Wp = torch.empty(N, K, dtype=torch.int32, device="cuda")
     L.artalk_op_pack_split(p(A), p(Ap), M * K, s); L.artalk_op_pack_split(p(W), p(Wp), N * K, s)
     Cc = torch.empty(M, N, device="cuda")
+    ref = A[:256].double() @ W.double().t() + b.double()
     line = f"{name:12s} M={M:6d} N={N:5d} K={K:4d} "
     for cfg, apk in variants:
+        if cfg >= 2 and M < 3000: continue
         best = 1e9
         n = 3 if M * N * K > 1e11 else 10
         for rnd in range(3):
@@ -29,5 +36,6 @@ for name, M, N, K in SHAPES:
                 L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wp), p(b), p(Cc), M, N, K, 0, cfg, s)
             e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / n)
-        line += f"| cfg{cfg}{'P' if apk else ' '}: {best*1e3:8.1f} us {2*M*N*K/best/1e9:6.1f} TF "
+        err = float((Cc[:256].double() - ref).abs().max() / ref.abs().max())
+        line += f"| cfg{cfg}{'P' if apk else ' '}: {best*1e3:8.1f} us {2*M*N*K/best/1e9:6.1f} TF e={err:.0e} "
     print(line, flush=True)
