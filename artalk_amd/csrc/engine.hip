@@ -87,6 +87,7 @@ struct artalk_model {
     struct PackRange { const float* base; int64_t n; unsigned int* packed; };
     std::vector<PackRange> wranges;   // every weight allocation and its packed f16x3 copy (built at finalize)
     int precision = 0;                // 0: fp32 MFMA everywhere, 1: f16x3 split GEMMs (heads stay fp32)
+    int stream_B = 0;                 // streams opened by artalk_stream_begin (history lives in the workspace)
     bool sticky_error = false;        // set by internal consistency checks inside the launch sequence; reported by artalk_infer
     // derived sizes
     int n_conv = 0; int conv_T[8]{}; int conv_S[8]{};   // valid frames / padded row stride per conv layer output
@@ -870,6 +871,7 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
     HIPCHK(m, hipMemcpyAsync(w.src_off, src.data(), C * sizeof(long), hipMemcpyHostToDevice, s));
     if (style_motion_dev && has_style) HIPCHK(m, hipMemcpyAsync(w.has_style, has_style, B, hipMemcpyHostToDevice, s));
     HIPCHK(m, hipStreamSynchronize(s));   // src/has_style are stack/heap temporaries of this call
+    m->stream_B = 0;   // the batch call reuses the workspace that holds the streaming history
     m->ev_used = 0; m->dom_events.clear(); m->marks.clear(); m->prof_stream = s;
     stage_mark(m, s, PB_OTHER);
     run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s);
@@ -924,6 +926,74 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
     stage_mark(m, s, PB_OTHER);
     HIPCHK(m, hipGetLastError());
     if (m->sticky_error) { m->sticky_error = false; return ARTALK_ESTATE; }
+    return ARTALK_OK;
+}
+
+// ---------------------------------------------------------------------------------- streaming
+// The path already produces 4-second blocks causally (app/models.py:92-114: chunk j needs only the re-encoded motion of
+// chunk j-1); these two calls expose that with the history kept in the model's workspace between calls.
+int artalk_stream_begin(artalk_model* m, int B, const float* style_motion_dev, const uint8_t* has_style, void* stream) {
+    if (!m || B <= 0) return ARTALK_EINVAL;
+    if (!m->finalized) return fail(m, ARTALK_ESTATE, "artalk_stream_begin before artalk_finalize_weights");
+    (void)hipSetDevice(m->device);
+    hipStream_t s = stream ? (hipStream_t)stream : m->own_stream;
+    if (B > m->ws.maxB || B > m->ws.maxC) { if (int rc = reserve(m, B, B)) return rc; }
+    Workspace& w = m->ws;
+    if (style_motion_dev && has_style) {
+        HIPCHK(m, hipMemcpyAsync(w.has_style, has_style, B, hipMemcpyHostToDevice, s));
+        HIPCHK(m, hipStreamSynchronize(s));
+    }
+    const int saved = m->profiling; m->profiling = 0;
+    run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s);
+    launch_enc_input_zero(m->vae_mean, m->vae_std, m->enc_pos, w.enc_in, B, s);
+    run_reencode(m, B, s);
+    m->profiling = saved;
+    m->stream_B = B;
+    HIPCHK(m, hipGetLastError());
+    return ARTALK_OK;
+}
+
+// audio_dev: [B][chunk_stride] f32, the next 64000 samples of every stream (zero padded by the caller at the end of a
+// clip); out_motion_dev: [B][out_stride] receives 100 x 106 codes per stream.
+int artalk_stream_chunk(artalk_model* m, const float* audio_dev, int64_t chunk_stride, float* out_motion_dev, int64_t out_stride,
+                        void* stream) {
+    if (!m || !audio_dev || !out_motion_dev) return ARTALK_EINVAL;
+    if (m->stream_B <= 0) return fail(m, ARTALK_ESTATE, "artalk_stream_chunk before artalk_stream_begin");
+    (void)hipSetDevice(m->device);
+    hipStream_t s = stream ? (hipStream_t)stream : m->own_stream;
+    const int B = m->stream_B;
+    Workspace& w = m->ws;
+    if (B > w.maxB) return fail(m, ARTALK_ESTATE, "workspace was re-reserved since artalk_stream_begin; begin again");
+    std::vector<long> src((size_t)B);
+    for (int b = 0; b < B; ++b) src[b] = (long)b * chunk_stride;
+    HIPCHK(m, hipMemcpyAsync(w.src_off, src.data(), B * sizeof(long), hipMemcpyHostToDevice, s));
+    HIPCHK(m, hipStreamSynchronize(s));
+    const int saved = m->profiling; m->profiling = 0;
+    for (int c0 = 0; c0 < B; c0 += w.G) run_wav2vec(m, audio_dev, c0, std::min(w.G, B - c0), nullptr, s);
+    linear(m, w.silu_cond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, B * kNTok, m->ada_n, kCond, ACT_NONE, nullptr, s,
+           m->precision == 1 ? LF_A_P8 : 0);
+    if (m->use_graphs) {
+        auto it = m->graphs.find(B);
+        if (it == m->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            HIPCHK(m, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            m->in_graph_body = true;
+            run_chunk_body(m, B, s);
+            m->in_graph_body = false;
+            HIPCHK(m, hipStreamEndCapture(s, &graph));
+            HIPCHK(m, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            it = m->graphs.emplace(B, exec).first;
+        }
+        HIPCHK(m, hipGraphLaunch(it->second, s));
+    } else {
+        run_chunk_body(m, B, s);
+    }
+    m->profiling = saved;
+    const size_t mrow = (size_t)100 * m->cfg.motion_dim * 4;
+    HIPCHK(m, hipMemcpy2DAsync(out_motion_dev, (size_t)out_stride * 4, w.motion_chunk, mrow, mrow, B, hipMemcpyDeviceToDevice, s));
+    HIPCHK(m, hipGetLastError());
     return ARTALK_OK;
 }
 

@@ -166,6 +166,56 @@ class BitwiseARModel:
                 "dom_launches", "dom_ms", "dom_flop"]
         return dict(zip(keys, list(out)))
 
+    # ------------------------------------------------------------------ streaming (chunk-at-a-time, persistent history)
+    @torch.no_grad()
+    def stream_begin(self, n_streams: int, style_motions: Optional[Sequence[Optional[torch.Tensor]]] = None):
+        """Open ``n_streams`` parallel streams: style condition + initial history (app/models.py:67-73,86-89)."""
+        if not self._loaded:
+            raise RuntimeError("load_state_dict must be called before inference")
+        dev = self._device
+        with torch.cuda.device(dev):
+            style_t, has = None, None
+            if style_motions is not None and any(s is not None for s in style_motions):
+                style_t = torch.zeros(n_streams, self.cfg.style_len, self.cfg.motion_dim, dtype=torch.float32, device=dev)
+                has = (C.c_uint8 * n_streams)()
+                for i, s in enumerate(style_motions):
+                    if s is not None:
+                        assert tuple(s.shape) == (self.cfg.style_len, self.cfg.motion_dim), f"Invalid style_motion shape: {tuple(s.shape)}."
+                        style_t[i] = s.to(device=dev, dtype=torch.float32)
+                        has[i] = 1
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=dev)
+            caller = torch.cuda.current_stream()
+            self._stream.wait_stream(caller)
+            rc = capi.lib().artalk_stream_begin(self._h, int(n_streams), capi.ptr(style_t),
+                                                C.cast(has, C.c_void_p) if has is not None else None, C.c_void_p(self._stream.cuda_stream))
+            caller.wait_stream(self._stream)
+            if style_t is not None:
+                style_t.record_stream(self._stream)
+        if rc != capi.OK:
+            raise RuntimeError("artalk_stream_begin failed: " + self._err())
+        self._n_streams = int(n_streams)
+
+    @torch.no_grad()
+    def stream_chunk(self, audio_chunks: torch.Tensor) -> torch.Tensor:
+        """Next 4 seconds of every stream: ``(n_streams, 64000)`` float32 (zero padded at a clip's end) -> ``(n_streams, 100, 106)``."""
+        B = getattr(self, "_n_streams", 0)
+        assert audio_chunks.shape == (B, self.cfg.samples_per_chunk), f"expected ({B}, {self.cfg.samples_per_chunk}) samples"
+        dev = self._device
+        with torch.cuda.device(dev):
+            x = audio_chunks.to(device=dev, dtype=torch.float32).contiguous()
+            out = torch.empty(B, 100, self.cfg.motion_dim, dtype=torch.float32, device=dev)
+            caller = torch.cuda.current_stream()
+            self._stream.wait_stream(caller)
+            rc = capi.lib().artalk_stream_chunk(self._h, capi.ptr(x), x.stride(0), capi.ptr(out), out.stride(0),
+                                                C.c_void_p(self._stream.cuda_stream))
+            caller.wait_stream(self._stream)
+            x.record_stream(self._stream)
+            out.record_stream(self._stream)
+        if rc != capi.OK:
+            raise RuntimeError("artalk_stream_chunk failed: " + self._err())
+        return out
+
     # ------------------------------------------------------------------ geometry of app/models.py:66,78-80
     def seq_length(self, n_samples: int) -> int:
         return math.ceil(n_samples / 16000 * 25.0)

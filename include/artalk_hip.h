@@ -85,6 +85,15 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
                  const float* style_motion_dev, const uint8_t* has_style, float* out_motion_dev, int64_t out_clip_stride,
                  uint8_t* out_bits_dev, uint8_t* out_hist_bits_dev, float* out_w2v_dev, void* stream);
 
+/* Streaming form of the same path (chunk-at-a-time, history kept in the model between calls): the reference
+ * loop body of app/models.py:92-114 for B parallel streams.  artalk_stream_begin computes the style condition and the initial
+ * history (app/models.py:67-73,86-89); every artalk_stream_chunk consumes the next 64000 samples of each stream
+ * (audio_dev [B][chunk_stride], zero padded by the caller at the end of a clip) and writes 100 x 106 codes per stream to
+ * out_motion_dev [B][out_stride].  A call to artalk_infer ends the streaming session (shared workspace). */
+int artalk_stream_begin(artalk_model* m, int B, const float* style_motion_dev, const uint8_t* has_style, void* stream);
+int artalk_stream_chunk(artalk_model* m, const float* audio_dev, int64_t chunk_stride, float* out_motion_dev, int64_t out_stride,
+                        void* stream);
+
 /* Savitzky-Golay smoothing of inference.py:89-95 on the device: in/out [T][106] f32, T >= 9. */
 int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, void* stream);
 

@@ -105,6 +105,31 @@ def test_batch_equals_single_runs():
     m.set_precision("f32")
 
 
+def test_streaming_equals_batch_call():
+    """Chunk-at-a-time streaming (history kept in the model) reproduces the one-shot call: same decisions, codes to 1e-5
+    (the wav2vec2 GEMMs see 1 chunk instead of 3 per launch, so only the fp32 summation order can differ)."""
+    from artalk_amd.synth import synth_audio, synth_style
+    m = get_gpu_model("tiny")
+    cfg, sd = get_state_dict("tiny")
+    mean, std = sd["basic_vae.motion_mean"].numpy(), sd["basic_vae.motion_std"].numpy()
+    audios = [torch.from_numpy(synth_audio(20 + i, 10.0)) for i in range(2)]
+    styles = [None, torch.from_numpy(synth_style(21, mean, std))]
+    want = m.inference_batch(audios, styles)
+    m.stream_begin(2, styles)
+    got = []
+    for j in range(3):
+        chunk = torch.zeros(2, 64000)
+        for b in range(2):
+            seg = audios[b][j * 64000:(j + 1) * 64000]
+            chunk[b, :seg.shape[0]] = seg
+        got.append(m.stream_chunk(chunk.cuda()))
+    got = torch.cat(got, dim=1)[:, :250]
+    for b in range(2):
+        assert (got[b] - want[b]).abs().max().item() < 1e-5
+    with pytest.raises(AssertionError):
+        m.stream_chunk(torch.zeros(3, 64000))
+
+
 def test_reference_call_surface():
     """BitwiseARModel.inference(batch) / ARTAvatarInferEngine.inference(audio) keep the reference's surface."""
     from artalk_amd.engine import ARTAvatarInferEngine
