@@ -638,6 +638,8 @@ int reserve(artalk_model* m, int maxB, int maxC) {
     w.s_att = F((int64_t)maxB * SL * S); w.s_ffn = F((int64_t)maxB * SL * c.style_ffn); w.s_tmp = F((int64_t)maxB * SL * S);
     for (void* p : m->ws_allocs)
         if (!p) return fail(m, ARTALK_EHIP, "hipMalloc failed while reserving workspace");
+    // the zero fills above run on the null stream; callers use non-blocking streams, which do not order against it
+    HIPCHK(m, hipDeviceSynchronize());
     return ARTALK_OK;
 }
 

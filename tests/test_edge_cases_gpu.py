@@ -1,0 +1,121 @@
+"""Edge cases of the path on the GPU against the CPU oracle (reduced-depth config so the oracle takes about a second):
+clip lengths around the chunk boundary, near-silent and silent audio (the per-chunk normalisation divides by std + 1e-6,
+app/modules/wav2vec.py:24-26), very short clips, large ragged batches, and the strict state_dict errors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import get_gpu_model, get_oracle, get_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+TAU = 2e-4     # a decision may differ from the oracle's only where the oracle's own logit margin is at rounding level
+
+
+def _oracle_run(audio, style=None):
+    o = get_oracle("tiny")
+    rec = {}
+    out = o.inference({"audio": audio[None], "style_motion": style[None] if style is not None else None}, record=rec)[0]
+    return out.numpy(), torch.cat(rec["bits"]).numpy(), torch.cat(rec["logit_margin"]).numpy()
+
+
+def _compare(got, bits, audio):
+    """Returns (max-abs err over the chunks before the first differing decision, #chunks compared); asserts that a
+    differing decision only happens at an oracle margin below TAU (every later decision depends on it)."""
+    want, wbits, margin = _oracle_run(audio)
+    assert got.shape == want.shape
+    good = wbits.shape[0]
+    for c in range(wbits.shape[0]):
+        d = bits[c] != wbits[c]
+        if d.any():
+            assert margin[c][d].min() < TAU, f"decision differs at chunk {c} with oracle margins {np.sort(margin[c][d])[:3]}"
+            good = c
+            break
+    n = min(good * 100, got.shape[0])
+    return (np.abs(got[:n] - want[:n]).max() if n else 0.0), good
+
+
+def _check(audio, precision):
+    m = get_gpu_model("tiny")
+    m.set_precision(precision)
+    got = m.inference_batch([audio], None, return_aux=True)[0].cpu().numpy()
+    bits = m.last_aux["bits"][0].cpu().numpy()
+    m.set_precision("f32")
+    return _compare(got, bits, audio)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("n_samples", [640 * 9, 16000, 63999, 64000, 64001, 64640, 128000 + 1])
+def test_lengths_around_chunk_boundaries(n_samples, precision):
+    """seq_length = ceil(N/640), chunks = ceil(seq/100), last chunk zero padded (app/models.py:66,78-85); N = 64001 leaves a
+    second chunk with a single non-zero sample (std ~ 1e-4): the harshest case for the per-chunk normalisation."""
+    from artalk_amd.synth import synth_audio
+    audio = torch.from_numpy(synth_audio(31, 20.0))[:n_samples].clone()
+    err, good = _check(audio, precision)
+    assert good >= 1 and err < 1e-3, (err, good)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_silence_and_constant_audio(precision):
+    for audio in (torch.zeros(70000), torch.full((40000,), 0.25)):
+        err, good = _check(audio, precision)
+        assert good >= 1 and err < 1e-3, (err, good)
+
+
+def test_too_short_for_savgol_raises_like_scipy():
+    from artalk_amd.engine import ARTAvatarInferEngine
+    cfg, sd = get_state_dict("tiny")
+    eng = ARTAvatarInferEngine.__new__(ARTAvatarInferEngine)
+    eng.ARTalk, eng.device, eng.style_motion, eng.clip_length, eng.fix_pose = get_gpu_model("tiny"), "cuda", None, 750, False
+    short = torch.zeros(640 * 8)                       # 8 frames < window 9
+    assert eng.ARTalk.inference({"audio": short[None], "style_motion": None}).shape == (1, 8, 106)
+    with pytest.raises(ValueError):
+        eng.inference(short)
+    with pytest.raises(ValueError):
+        eng.ARTalk.inference_batch([torch.zeros(0)])
+    assert eng.ARTalk.inference_batch([]) == []
+
+
+def test_large_ragged_batch():
+    """70 clips of 1..3 chunks in one call, as the FIRST call of a fresh model (the workspace is allocated inside the call;
+    this once exposed zero-fills racing the first kernels): equals the oracle per clip."""
+    from artalk_amd.synth import synth_audio
+    from artalk_amd.model import BitwiseARModel
+    cfg, sd = get_state_dict("tiny")
+    m = BitwiseARModel(cfg).eval().to("cuda")
+    m.load_state_dict(sd, strict=True)
+    m.set_precision("f16x3")
+    lens = [16000 + 5000 * (i % 31) for i in range(70)]
+    audios = [torch.from_numpy(synth_audio(100 + i, 11.0))[:n].clone() for i, n in enumerate(lens)]
+    outs = m.inference_batch(audios, return_aux=True)
+    bits = [b.cpu().numpy() for b in m.last_aux["bits"]]
+    m.set_precision("f32")
+    assert [o.shape[0] for o in outs] == [m.seq_length(n) for n in lens]
+    for i in (0, 17, 30, 69):
+        err, good = _compare(outs[i].cpu().numpy(), bits[i], audios[i])
+        assert good >= 1 and err < 1e-3, (i, err, good)
+
+
+def test_strict_state_dict_errors():
+    """load_state_dict(strict=True) semantics of reference inference.py:28 through the C ABI."""
+    from artalk_amd.model import BitwiseARModel
+    cfg, sd = get_state_dict("tiny")
+    bad = dict(sd)
+    bad["not.a.key"] = torch.zeros(3)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        BitwiseARModel(cfg).to("cuda").load_state_dict(bad)
+    bad = dict(sd)
+    del bad["logits_head.bias"]
+    with pytest.raises(RuntimeError, match="Missing key"):
+        BitwiseARModel(cfg).to("cuda").load_state_dict(bad)
+    bad = dict(sd)
+    bad["vqfeat_embed.weight"] = sd["vqfeat_embed.weight"][:, :16].contiguous()
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        BitwiseARModel(cfg).to("cuda").load_state_dict(bad)
+    bad = dict(sd)
+    bad["lvl_idx"] = sd["lvl_idx"].flip(-1).contiguous()
+    with pytest.raises(RuntimeError, match="lvl_idx"):
+        BitwiseARModel(cfg).to("cuda").load_state_dict(bad)
+    with pytest.raises(RuntimeError, match="before inference"):
+        BitwiseARModel(cfg).to("cuda").inference_batch([torch.zeros(16000)])
