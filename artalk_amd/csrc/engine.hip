@@ -1088,7 +1088,7 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
     GemmArgs g;
     g.A = (const float*)A; g.a_packed = a_packed; g.lda = lda; g.W = nullptr; g.Wp = (const unsigned int*)Wp; g.ldw = K; g.bias = bias;
     g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act; g.force_cfg = force_cfg;
-    if (force_cfg >= 2) {   // LDS-DMA pipelined kernel (needs both operands in P8); 3 / 5 select the pipeline depth, 2 = default
+    if (force_cfg >= 2) {   // LDS-DMA pipelined kernel (needs both operands in P8); 3 / 5 select the pipeline depth, 6 = 256x128 tiles, 2 = default
         if (!a_packed) return ARTALK_EINVAL;
         g.force_cfg = force_cfg == 2 ? -1 : force_cfg;
         launch_gemm_p8(g, (hipStream_t)stream);

@@ -235,10 +235,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
 //   LDS stage: A 128 rows x 128 B, then W 128 rows x 128 B, rows unpadded (a DMA wave-instruction writes 1 KiB = 8 rows);
 //   16-byte chunk c of row r lives at physical chunk c ^ ((r >> 1) & 7): the XOR is applied to the per-lane SOURCE address
 //   of the DMA and again on the fragment read (same involution), which makes the ds_read_b128 fragment reads conflict-free.
-template <int STAGES>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int UNIT>
+__device__ __forceinline__ void wait_vmcnt_units(int units) {   // at most `units` groups of UNIT DMA instructions stay in flight
+    if (units >= 3) wait_vmcnt<3 * UNIT>();
+    else if (units == 2) wait_vmcnt<2 * UNIT>();
+    else if (units == 1) wait_vmcnt<UNIT>();
+    else wait_vmcnt<0>();
+}
+
+// BM = 128: waves 2 x 4, wave tile 64 x 32, 4 stages of 32 KiB.  BM = 256: waves 4 x 2, wave tile 64 x 64, 3 stages of 48 KiB
+// (3/4 of the operand bytes per flop).
+template <int BM, int STAGES>
 __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
-    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int BN = 128, BK = 32;
+    constexpr int WN_WAVES = (BM == 128) ? 4 : 2;          // waves along N
+    constexpr int TN = BN / WN_WAVES / 32;                 // n-tiles per wave (1 or 2); m-tiles per wave = 2
+    constexpr int APIECES = BM / 64, WPIECES = 2;          // 1-KiB DMA pieces per wave per stage
+    constexpr int NDMA = APIECES + WPIECES;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static_assert(STAGES * STAGE_BYTES <= 160 * 1024, "LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
 
     const int tid = threadIdx.x;
@@ -249,7 +266,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        constexpr int GM = 4;
+        constexpr int GM = (BM == 128) ? 4 : 2;
         const int width = GM * tiles_n;
         const int group = idx / width, first_m = group * GM;
         const int gsz = min(tiles_m - first_m, GM);
@@ -259,50 +276,58 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
     }
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // ---- DMA addressing: per stage each wave issues 2 A pieces and 2 W pieces of 1 KiB (8 rows x 128 B) ----
-    const int prow = lane >> 3, pchunk = lane & 7;            // row within the piece, physical chunk
-    const unsigned char* asrc[2];
-    const unsigned char* wsrc[2];
-    int lds_piece[4];
+    // ---- DMA addressing: 1-KiB pieces (8 rows x 128 B); lane = (row in piece, physical chunk) ----
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const unsigned char* asrc[APIECES];
+    const unsigned char* wsrc[WPIECES];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int ra = (wave * 2 + q) * 8 + prow;             // tile row 0..127
-        const int ca = pchunk ^ ((ra >> 1) & 7);              // logical chunk fetched into physical slot pchunk
-        const int gm = min(m0 + ra, g.M - 1), gn = min(n0 + ra, g.N - 1);   // clamp: rows >= M/N are never stored
-        asrc[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda) * 4 + ca * 16;
-        wsrc[q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw) * 4 + ca * 16;
-        lds_piece[q] = (wave * 2 + q) * 1024;
-        lds_piece[2 + q] = BM * 128 + (wave * 2 + q) * 1024;
+    for (int q = 0; q < APIECES; ++q) {
+        const int ra = (wave * APIECES + q) * 8 + prow;                 // tile row 0..BM-1
+        const int gm = min(m0 + ra, g.M - 1);                           // clamp: rows >= M are never stored
+        asrc[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda) * 4 + ((pchunk ^ ((ra >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int q = 0; q < WPIECES; ++q) {
+        const int rw = (wave * WPIECES + q) * 8 + prow;
+        const int gn = min(n0 + rw, g.N - 1);
+        wsrc[q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw) * 4 + ((pchunk ^ ((rw >> 1) & 7)) << 4);
     }
     auto issue = [&](int kt, int buf) {
         unsigned char* base = smem_p8 + buf * STAGE_BYTES;
         const long koff = (long)kt * (BK * 4);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < APIECES; ++q)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[q] + koff),
-                                             (__attribute__((address_space(3))) void*)(base + lds_piece[q]), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + (wave * APIECES + q) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < WPIECES; ++q)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + koff),
-                                             (__attribute__((address_space(3))) void*)(base + lds_piece[2 + q]), 16, 0, 0);
-        }
+                                             (__attribute__((address_space(3))) void*)(base + BM * 128 + (wave * WPIECES + q) * 1024), 16, 0, 0);
     };
 
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
     const int r = lane & 31, h = lane >> 5;
-    int a_row_off[2], a_key[2];
+    int a_row_off[2], a_key[2], w_row_off[TN], w_key[TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = wm * 64 + i * 32 + r;
         a_row_off[i] = row * 128;
         a_key[i] = (row >> 1) & 7;
     }
-    const int wrow = wn * 32 + r;
-    const int w_row_off = BM * 128 + wrow * 128, w_key = (wrow >> 1) & 7;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * (32 * TN) + j * 32 + r;
+        w_row_off[j] = BM * 128 + row * 128;
+        w_key[j] = (row >> 1) & 7;
+    }
 
-    f32x16 accm[2], accx[2];
+    f32x16 accm[2][TN], accx[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { accm[i][e] = 0.f; accx[i][e] = 0.f; }
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { accm[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
 
     const int nk = g.K / BK;
 #pragma unroll
@@ -313,79 +338,75 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
     // barrier) sit under matrix work instead of in front of it:
     //   iteration kt:  read kb=1 frags of stage kt | MFMA kb=0 | wait stage kt+1, barrier, DMA stage kt+S-1 |
     //                  read kb=0 frags of stage kt+1 | MFMA kb=1
-    auto wait_stage = [&](int st) {   // stage st landed for THIS wave: at most `younger` later stages (4 DMA instr each) in flight
-        const int younger = min(STAGES - 3, nk - 1 - st);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    auto read_frags = [&](const unsigned char* base, int kb, f16x8 (&ah)[2], f16x8 (&al)[2], f16x8& bh, f16x8& bl) {
+    auto read_frags = [&](const unsigned char* base, int kb, f16x8 (&ah)[2], f16x8 (&al)[2], f16x8 (&bh)[TN], f16x8 (&bl)[TN]) {
         const int c = (kb * 2 + h) * 2;               // logical chunk of the hi fragment; lo = c + 1
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             ah[i] = *reinterpret_cast<const f16x8*>(base + a_row_off[i] + ((c ^ a_key[i]) << 4));
             al[i] = *reinterpret_cast<const f16x8*>(base + a_row_off[i] + (((c + 1) ^ a_key[i]) << 4));
         }
-        bh = *reinterpret_cast<const f16x8*>(base + w_row_off + ((c ^ w_key) << 4));
-        bl = *reinterpret_cast<const f16x8*>(base + w_row_off + (((c + 1) ^ w_key) << 4));
-    };
-    auto mfma6 = [&](const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8& bh, const f16x8& bl) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, accm[i], 0, 0, 0);
-            accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, accx[i], 0, 0, 0);
-            accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, accx[i], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+            bh[j] = *reinterpret_cast<const f16x8*>(base + w_row_off[j] + ((c ^ w_key[j]) << 4));
+            bl[j] = *reinterpret_cast<const f16x8*>(base + w_row_off[j] + (((c + 1) ^ w_key[j]) << 4));
         }
     };
+    auto mfmas = [&](const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
+                accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+            }
+    };
 
-    f16x8 ah0[2], al0[2], bh0, bl0, ah1[2], al1[2], bh1, bl1;
-    {   // stage 0: the DMA prologue left stages 1..STAGES-2 younger than it
-        const int younger = min(STAGES - 2, nk - 1);
-        if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        read_frags(smem_p8, 0, ah0, al0, bh0, bl0);
-    }
+    f16x8 ah0[2], al0[2], bh0[TN], bl0[TN], ah1[2], al1[2], bh1[TN], bl1[TN];
+    wait_vmcnt_units<NDMA>(min(STAGES - 2, nk - 1));   // stage 0 landed (the prologue left up to STAGES-2 younger stages in flight)
+    __builtin_amdgcn_s_barrier();
+    read_frags(smem_p8, 0, ah0, al0, bh0, bl0);
     for (int kt = 0; kt < nk; ++kt) {
         const unsigned char* base = smem_p8 + (kt % STAGES) * STAGE_BYTES;
         read_frags(base, 1, ah1, al1, bh1, bl1);
-        mfma6(ah0, al0, bh0, bl0);
+        mfmas(ah0, al0, bh0, bl0);
         if (kt + 1 < nk) {
-            wait_stage(kt + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of stage kt are back before anyone may overwrite it
-            __builtin_amdgcn_s_barrier();                          // stage kt+1 visible to all; all waves are done with stage kt-1
+            wait_vmcnt_units<NDMA>(min(STAGES - 3, nk - 2 - kt));    // stage kt+1 landed for this wave
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // my reads of stage kt are back before anyone may overwrite it
+            __builtin_amdgcn_s_barrier();                             // stage kt+1 visible to all; all waves are done with stage kt-1
             if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);   // reuses the buffer of stage kt-1
             read_frags(smem_p8 + ((kt + 1) % STAGES) * STAGE_BYTES, 0, ah0, al0, bh0, bl0);
         }
-        mfma6(ah1, al1, bh1, bl1);
+        mfmas(ah1, al1, bh1, bl1);
     }
 
     const float* __restrict__ bias = g.bias;
     float* __restrict__ C = g.C;
     const float* R = g.R;
-    const int col = n0 + wn * 32 + r;
-    const bool cok = col < g.N;
-    const float bv = (bias && cok) ? bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (32 * TN) + j * 32 + r;
+        const bool cok = col < g.N;
+        const float bv = (bias && cok) ? bias[col] : 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (row < g.M && cok) {
-                float v = (accm[i][e] + accx[i][e] * kLoInv) + bv;
-                v = apply_act_rt(v, g.act);
-                if (g.gate) v *= g.gate[(long)map_row(g.gmap, row) * g.ldg + col];
-                const long crow = map_row(g.cmap, row);
-                if (R) v += R[crow * g.ldr + col];
-                if (g.c_p8) {   // hand the result to the next split GEMM already in P8 (element col of the row -> hi/lo planes of its group)
-                    _Float16* o = reinterpret_cast<_Float16*>(C + crow * g.ldc + (col & ~7));
-                    const _Float16 hh = (_Float16)v;
-                    o[col & 7] = hh;
-                    o[8 + (col & 7)] = (_Float16)((v - (float)hh) * kLoScale);
-                } else {
-                    C[crow * g.ldc + col] = v;
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < g.M && cok) {
+                    float v = (accm[i][j][e] + accx[i][j][e] * kLoInv) + bv;
+                    v = apply_act_rt(v, g.act);
+                    if (g.gate) v *= g.gate[(long)map_row(g.gmap, row) * g.ldg + col];
+                    const long crow = map_row(g.cmap, row);
+                    if (R) v += R[crow * g.ldr + col];
+                    if (g.c_p8) {   // hand the result to the next split GEMM already in P8 (element col -> hi/lo planes of its group)
+                        _Float16* o = reinterpret_cast<_Float16*>(C + crow * g.ldc + (col & ~7));
+                        const _Float16 hh = (_Float16)v;
+                        o[col & 7] = hh;
+                        o[8 + (col & 7)] = (_Float16)((v - (float)hh) * kLoScale);
+                    } else {
+                        C[crow * g.ldc + col] = v;
+                    }
                 }
             }
         }
@@ -394,11 +415,12 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
 
 void launch_gemm_p8(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return;
-    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
-    switch (g.force_cfg) {   // tuning: pipeline depth (default 4 stages = 128 KiB of LDS, 2 K tiles in flight + 1 being read ahead)
-        case 3: hipLaunchKernelGGL(gemm_p8_kernel<3>, dim3(tiles), dim3(512), 3 * 256 * 128, s, g); break;
-        case 5: hipLaunchKernelGGL(gemm_p8_kernel<5>, dim3(tiles), dim3(512), 5 * 256 * 128, s, g); break;
-        default: hipLaunchKernelGGL(gemm_p8_kernel<4>, dim3(tiles), dim3(512), 4 * 256 * 128, s, g); break;
+    const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t256 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
+    switch (g.force_cfg) {   // tuning: 3 / 5 = pipeline depth of the 128x128 kernel, 6 = 256x128 tiles (3 stages of 48 KiB)
+        case 3: hipLaunchKernelGGL((gemm_p8_kernel<128, 3>), dim3(t128), dim3(512), 3 * 256 * 128, s, g); break;
+        case 5: hipLaunchKernelGGL((gemm_p8_kernel<128, 5>), dim3(t128), dim3(512), 5 * 256 * 128, s, g); break;
+        case 6: hipLaunchKernelGGL((gemm_p8_kernel<256, 3>), dim3(t256), dim3(512), 3 * 384 * 128, s, g); break;
+        default: hipLaunchKernelGGL((gemm_p8_kernel<128, 4>), dim3(t128), dim3(512), 4 * 256 * 128, s, g); break;
     }
 }
 bool gemm_p8_eligible(const GemmArgs& g) {

@@ -9,7 +9,7 @@ p = lambda t: C.c_void_p(t.data_ptr())
 SHAPES = [("w2v qkv", 19200, 3072, 1024), ("w2v out", 19200, 1024, 1024), ("w2v ff1", 19200, 4096, 1024), ("w2v ff2", 19200, 1024, 4096),
           ("conv1", 614400, 512, 1536), ("ada", 5792, 56832, 1024), ("ar ffn1 p4", 3200, 3072, 768), ("ar ffn2 p4", 3200, 768, 3072),
           ("ar qkv p2", 800, 2304, 768), ("ar ffn2 p2", 800, 768, 3072)]
-variants = [(0, 1), (3, 1), (2, 1), (5, 1)]   # (tile cfg, A packed): cfg 2 = LDS-DMA pipelined kernel
+variants = [(0, 0), (1, 1), (2, 1), (6, 1)]   # (cfg, A packed): 0/1 register-staged 128x128 / 64x64, 2 LDS-DMA 128x128, 6 LDS-DMA 256x128   # (tile cfg, A packed): cfg 2 = LDS-DMA pipelined kernel
 only = os.environ.get("GEMM_ONLY")
 if only:
     SHAPES = [x for x in SHAPES if x[0] in only.split(",")]
