@@ -19,7 +19,7 @@ namespace artalk {
 template <int HD>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     constexpr int KB = 64;
-    constexpr int KLD = HD + 8, VLD = HD + 4;
+    constexpr int KLD = HD + 8, VLD = HD + 16;   // V rows: lane r reads NDT consecutive floats (one ds_read_b128 for HD = 64)
     constexpr int NC = HD / 16;    // 16-byte chunks of a q/k row held per lane (chunk index g + 4c)
     constexpr int NDT = HD / 16;   // 16-wide d tiles of O^T
     constexpr int TPR = HD / 4;    // staging threads per row
@@ -105,11 +105,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         __syncthreads();
         if (!wave_active) continue;
 
-        // ---- S^T tiles: st[t][j] = S[key kb0+16t+4g+j][query qi] ----
+        // ---- S^T tiles: st[t][j] = S[key kb0+16t+4g+j][query qi]; 16-key tiles entirely past Lk are skipped (wave-uniform) ----
+        const int ntile = min(4, (a.Lk - kb0 + 15) >> 4);
         f32x4 st[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (t < ntile)
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (t * 16 + r) * KLD + 4 * (g + 4 * c));
@@ -147,15 +149,26 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         l_part = l_part * alpha + ps;
 #pragma unroll
         for (int d = 0; d < NDT; ++d) ot[d] *= alpha;
-        // ---- O^T += V^T P^T: step (t,j): k-slot g <-> key 16t+4g+j; A = V[key][16d + r], B = st[t][j] ----
+        // ---- O^T += V^T P^T: step (t,j): k-slot g <-> key 16t+4g+j; B = st[t][j].  Output row i of d-tile dd is d = NDT*i + dd,
+        // so lane r's A values for the NDT tiles are V[key][NDT*r .. NDT*r+NDT-1]: one vector LDS read instead of NDT scalar ones.
 #pragma unroll
         for (int t = 0; t < 4; ++t)
+            if (t < ntile)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float* vrow = Vs + (t * 16 + 4 * g + j) * VLD + r;
+                const float* vrow = Vs + (t * 16 + 4 * g + j) * VLD + NDT * r;
+                float vv[NDT];
+                if constexpr (NDT == 4) {
+                    const f32x4 tv = *reinterpret_cast<const f32x4*>(vrow);
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) vv[d] = tv[d];
+                } else {
+                    const float2 tv = *reinterpret_cast<const float2*>(vrow);
+                    vv[0] = tv.x; vv[NDT - 1] = tv.y;
+                }
 #pragma unroll
                 for (int d = 0; d < NDT; ++d)
-                    ot[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[d * 16], st[t][j], ot[d], 0, 0, 0);
+                    ot[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[d], st[t][j], ot[d], 0, 0, 0);
             }
     }
     if (!wave_active) return;
@@ -165,11 +178,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     if (qvalid) {
         const float inv = 1.0f / l;
         float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
+        // ot[dd][reg] = O[d = NDT*(4g+reg) + dd]: for each reg the NDT tiles hold NDT consecutive d
 #pragma unroll
-        for (int d = 0; d < NDT; ++d) {
-            f32x4 o = ot[d] * inv;
-            if (a.out_p8) store_p8x4(op, d * 16 + 4 * g, o[0], o[1], o[2], o[3]);   // op is 32-byte aligned (HD % 8 == 0)
-            else *reinterpret_cast<f32x4*>(op + d * 16 + 4 * g) = o;   // O^T rows 4g..4g+3 of tile d = 4 consecutive d
+        for (int reg = 0; reg < 4; ++reg) {
+            const int d0 = NDT * (4 * g + reg);
+            if constexpr (NDT == 4) {
+                const float o0 = ot[0][reg] * inv, o1 = ot[1][reg] * inv, o2 = ot[2][reg] * inv, o3 = ot[3][reg] * inv;
+                if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3);   // op is 32-byte aligned (HD % 8 == 0)
+                else { f32x4 o = {o0, o1, o2, o3}; *reinterpret_cast<f32x4*>(op + d0) = o; }
+            } else {
+                *reinterpret_cast<float2*>(op + d0) = make_float2(ot[0][reg] * inv, ot[NDT - 1][reg] * inv);
+            }
         }
     }
 }
