@@ -19,7 +19,7 @@ DTYPE_F32, DTYPE_I64 = 0, 1
 # every symbol include/artalk_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "artalk_create", "artalk_destroy", "artalk_last_error", "artalk_set_tensor", "artalk_finalize_weights",
-    "artalk_reserve", "artalk_workspace_bytes", "artalk_weight_bytes", "artalk_infer", "artalk_stream_begin", "artalk_stream_chunk", "artalk_savgol",
+    "artalk_reserve", "artalk_workspace_bytes", "artalk_weight_bytes", "artalk_infer", "artalk_stream_begin", "artalk_stream_chunk", "artalk_savgol", "artalk_flame_create", "artalk_flame_verts", "artalk_flame_destroy", "artalk_flame_last_error",
     "artalk_set_profiling", "artalk_get_profile", "artalk_set_graphs", "artalk_set_precision",
     "artalk_op_gemm", "artalk_op_gemm_ex", "artalk_op_gemm_f16s", "artalk_op_pack_split", "artalk_op_gemm_f16s_packed", "artalk_op_mfma_f32_peak", "artalk_op_layernorm", "artalk_op_attention", "artalk_op_w2v_front", "artalk_op_resample_mean", "artalk_op_pool_silu",
     "artalk_op_bsq_history",
@@ -104,6 +104,14 @@ def lib() -> C.CDLL:
     L.artalk_stream_begin.restype = i32
     L.artalk_stream_chunk.argtypes = [vp, vp, i64, vp, i64, vp]
     L.artalk_stream_chunk.restype = i32
+    L.artalk_flame_create.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, C.POINTER(vp)]
+    L.artalk_flame_create.restype = i32
+    L.artalk_flame_verts.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.artalk_flame_verts.restype = i32
+    L.artalk_flame_destroy.argtypes = [vp]
+    L.artalk_flame_destroy.restype = None
+    L.artalk_flame_last_error.argtypes = [vp]
+    L.artalk_flame_last_error.restype = C.c_char_p
     L.artalk_savgol.argtypes = [vp, vp, vp, i32, vp]
     L.artalk_savgol.restype = i32
     L.artalk_set_profiling.argtypes = [vp, i32]

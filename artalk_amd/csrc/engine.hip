@@ -1159,4 +1159,103 @@ int artalk_op_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }
 
+// ---------------------------------------------------------------------------------- FLAME vertices
+struct artalk_flame {
+    int device = 0, V = 0, NB = 0, NBp = 0, P = 0, Pp = 0, cap = 0;
+    float scale = 1.f;
+    float *v_template = nullptr, *shapedirs = nullptr, *posedirs = nullptr, *jreg = nullptr, *weights = nullptr;
+    int* parents = nullptr;
+    float *betas = nullptr, *feat = nullptr, *rot = nullptr, *J = nullptr, *vshaped = nullptr, *vposed = nullptr;
+    std::vector<void*> allocs, ws;
+    std::string err;
+};
+
+static thread_local std::string g_flame_error;
+const char* artalk_flame_last_error(const artalk_flame* f) { return f ? f->err.c_str() : g_flame_error.c_str(); }
+
+void artalk_flame_destroy(artalk_flame* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : f->allocs) if (p) (void)hipFree(p);
+    for (void* p : f->ws) if (p) (void)hipFree(p);
+    delete f;
+}
+
+// Host arrays in the layouts of the reference's FLAMEModel buffers (app/flame_model/FLAME.py:36-45):
+// v_template [V][3], shapedirs [V][3][NB], posedirs_t [V*3][P] (= the reference buffer transposed), J_regressor [5][V],
+// parents [5] (parents[0] = -1), lbs_weights [V][5].
+int artalk_flame_create(int device_id, int V, int NB, int P, const float* v_template, const float* shapedirs, const float* posedirs_t,
+                        const float* J_regressor, const int32_t* parents, const float* lbs_weights, float scale, artalk_flame** out) {
+    if (!out || !v_template || !shapedirs || !posedirs_t || !J_regressor || !parents || !lbs_weights || V <= 0 || NB <= 0 || P != 36) {
+        g_flame_error = "bad argument (FLAME has 5 joints: posedirs must have 36 rows)";
+        return ARTALK_EINVAL;
+    }
+    if (parents[0] != -1) { g_flame_error = "parents[0] must be -1"; return ARTALK_EINVAL; }
+    for (int j = 1; j < 5; ++j) if (parents[j] < 0 || parents[j] >= j) { g_flame_error = "parents must form a tree in topological order"; return ARTALK_EINVAL; }
+    if (hipSetDevice(device_id) != hipSuccess) { g_flame_error = "hipSetDevice failed"; return ARTALK_EHIP; }
+    artalk_flame* f = new artalk_flame();
+    f->device = device_id; f->V = V; f->NB = NB; f->P = P; f->scale = scale;
+    f->NBp = (NB + 31) / 32 * 32; f->Pp = 64;
+    auto up = [&](const float* h, int64_t rows, int64_t cols, int64_t cols_pad) -> float* {
+        float* d = dalloc_in<float>(f->allocs, rows * cols_pad);
+        if (!d) return nullptr;
+        if (cols == cols_pad) { (void)hipMemcpy(d, h, rows * cols * 4, hipMemcpyHostToDevice); }
+        else (void)hipMemcpy2D(d, cols_pad * 4, h, cols * 4, cols * 4, rows, hipMemcpyHostToDevice);
+        return d;
+    };
+    f->v_template = up(v_template, 1, (int64_t)V * 3, (int64_t)V * 3);
+    f->shapedirs = up(shapedirs, (int64_t)V * 3, NB, f->NBp);       // GEMM weight [N = 3V][K = NB padded]
+    f->posedirs = up(posedirs_t, (int64_t)V * 3, P, f->Pp);
+    f->jreg = up(J_regressor, 5, V, V);
+    f->weights = up(lbs_weights, V, 5, 5);
+    f->parents = dalloc_in<int>(f->allocs, 5);
+    for (void* p : f->allocs) if (!p) { g_flame_error = "hipMalloc failed"; artalk_flame_destroy(f); return ARTALK_EHIP; }
+    (void)hipMemcpy(f->parents, parents, 5 * sizeof(int), hipMemcpyHostToDevice);
+    if (hipDeviceSynchronize() != hipSuccess) { g_flame_error = "upload failed"; artalk_flame_destroy(f); return ARTALK_EHIP; }
+    *out = f;
+    return ARTALK_OK;
+}
+
+// betas_dev [T][NB] (shape ++ expression), full_pose_dev [T][15] (global, neck, jaw, eye_l, eye_r axis-angles: FLAME.py:131-136)
+// -> out_dev [T][V][3] = vertices * scale
+int artalk_flame_verts(artalk_flame* f, const float* betas_dev, const float* full_pose_dev, int T, float* out_dev, void* stream) {
+    if (!f || !betas_dev || !full_pose_dev || !out_dev || T <= 0) return ARTALK_EINVAL;
+    (void)hipSetDevice(f->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (T > f->cap) {
+        (void)hipDeviceSynchronize();
+        for (void* p : f->ws) if (p) (void)hipFree(p);
+        f->ws.clear();
+        const int64_t N = (int64_t)f->V * 3;
+        f->betas = dalloc_in<float>(f->ws, (int64_t)T * f->NBp);
+        f->feat = dalloc_in<float>(f->ws, (int64_t)T * f->Pp);
+        f->rot = dalloc_in<float>(f->ws, (int64_t)T * 45);
+        f->J = dalloc_in<float>(f->ws, (int64_t)T * 15);
+        f->vshaped = dalloc_in<float>(f->ws, T * N);
+        f->vposed = dalloc_in<float>(f->ws, T * N);
+        for (void* p : f->ws) if (!p) { f->err = "hipMalloc failed"; f->cap = 0; return ARTALK_EHIP; }
+        (void)hipDeviceSynchronize();   // zero fills run on the null stream
+        f->cap = T;
+    }
+    const int N = f->V * 3;
+    // betas into the K-padded GEMM operand (pad columns stay zero from allocation)
+    if (hipMemcpy2DAsync(f->betas, (size_t)f->NBp * 4, betas_dev, (size_t)f->NB * 4, (size_t)f->NB * 4, T, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        f->err = "copy failed"; return ARTALK_EHIP;
+    }
+    GemmArgs g;     // v_shaped = v_template + betas . shapedirs^T      (exact fp32 MFMA)
+    g.A = f->betas; g.lda = f->NBp; g.W = f->shapedirs; g.ldw = f->NBp; g.C = f->vshaped; g.ldc = N; g.R = f->v_template; g.ldr = 0;
+    g.M = T; g.N = N; g.K = f->NBp;
+    launch_gemm(g, s);
+    launch_flame_joints(f->vshaped, f->jreg, f->J, T, f->V, s);
+    launch_flame_pose(full_pose_dev, f->rot, f->feat, T, f->Pp, s);
+    GemmArgs p;     // v_posed = v_shaped + pose_feature . posedirs
+    p.A = f->feat; p.lda = f->Pp; p.W = f->posedirs; p.ldw = f->Pp; p.C = f->vposed; p.ldc = N; p.R = f->vshaped; p.ldr = N;
+    p.M = T; p.N = N; p.K = f->Pp;
+    launch_gemm(p, s);
+    launch_flame_skin(f->vposed, f->rot, f->J, f->parents, f->weights, out_dev, T, f->V, f->scale, s);
+    if (hipGetLastError() != hipSuccess) { f->err = "kernel launch failed"; return ARTALK_EHIP; }
+    return ARTALK_OK;
+}
+
 }  // extern "C"

@@ -131,6 +131,11 @@ double launch_mfma_f32_peak(float* out, int blocks, int iters, int nacc, hipStre
 // sinc resampler + channel mean: x [nch][n] -> out [n_out], taps [new][2*width+orig]
 void launch_resample_mean(const float* x, int nch, int n, const float* taps, int orig, int nw, int width, float* out, int n_out,
                           hipStream_t s);
+// FLAME linear blend skinning (flame.hip)
+void launch_flame_pose(const float* pose, float* rot, float* feat, int T, int ldf, hipStream_t s);
+void launch_flame_joints(const float* vs, const float* jreg, float* J, int T, int V, hipStream_t s);
+void launch_flame_skin(const float* vposed, const float* rot, const float* J, const int* parents, const float* weights, float* out,
+                       int T, int V, float scale, hipStream_t s);
 void init_ms_tables();   // uploads the (tiny) interpolation tables to __constant__ memory; idempotent
 
 }  // namespace artalk

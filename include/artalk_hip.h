@@ -94,6 +94,18 @@ int artalk_stream_begin(artalk_model* m, int B, const float* style_motion_dev, c
 int artalk_stream_chunk(artalk_model* m, const float* audio_dev, int64_t chunk_stride, float* out_motion_dev, int64_t out_stride,
                         void* stream);
 
+/* FLAME linear blend skinning: the consumer behind BITWISE_VAE.get_flame_verts (bitwise_vae.py:43-57) ->
+ * FLAMEModel.forward(no_lmks=True) (app/flame_model/FLAME.py:117-142) -> lbs (app/flame_model/lbs.py:142-233).  Host arrays in
+ * the layouts of the reference's buffers: v_template [V][3], shapedirs [V][3][NB], posedirs_t [V*3][36] (the reference buffer
+ * transposed), J_regressor [5][V], parents [5], lbs_weights [V][5].  artalk_flame_verts: betas_dev [T][NB] (shape ++ expression),
+ * full_pose_dev [T][15] (global, neck, jaw, eyes) -> out_dev [T][V][3], already multiplied by `scale`. */
+typedef struct artalk_flame artalk_flame;
+int artalk_flame_create(int device_id, int V, int NB, int P, const float* v_template, const float* shapedirs, const float* posedirs_t,
+                        const float* J_regressor, const int32_t* parents, const float* lbs_weights, float scale, artalk_flame** out);
+int artalk_flame_verts(artalk_flame* f, const float* betas_dev, const float* full_pose_dev, int T, float* out_dev, void* stream);
+void artalk_flame_destroy(artalk_flame* f);
+const char* artalk_flame_last_error(const artalk_flame* f);
+
 /* Savitzky-Golay smoothing of inference.py:89-95 on the device: in/out [T][106] f32, T >= 9. */
 int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, void* stream);
 
