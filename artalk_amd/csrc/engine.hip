@@ -64,6 +64,7 @@ struct Workspace {
     float *x = nullptr, *xmod = nullptr, *attn_out = nullptr, *ffn_h = nullptr, *logits = nullptr;
     float *fhat = nullptr, *nextfeat = nullptr;
     float* splitk = nullptr; int64_t splitk_floats = 0;   // partial sums of split-K GEMMs
+    float* splitk_b[4] = {nullptr, nullptr, nullptr, nullptr};   // one scratch per concurrent branch of the AR body (splitk_b[0] == splitk)
     uint8_t *bits = nullptr, *hist_bits = nullptr, *has_style = nullptr;
     // VAE
     float *prev_fdec = nullptr, *msfeat = nullptr, *dec_x = nullptr, *vh = nullptr, *vln = nullptr, *vqkv = nullptr;
@@ -88,6 +89,7 @@ struct artalk_model {
     std::vector<PackRange> wranges;   // every weight allocation and its packed f16x3 copy (built at finalize)
     int precision = 0;                // 0: fp32 MFMA everywhere, 1: f16x3 split GEMMs (heads stay fp32)
     int stream_B = 0;                 // streams opened by artalk_stream_begin (history lives in the workspace)
+    Workspace* view = nullptr;        // workspace view (clip sub-range) the body launchers currently work on; null = m->ws
     bool sticky_error = false;        // set by internal consistency checks inside the launch sequence; reported by artalk_infer
     // derived sizes
     int n_conv = 0; int conv_T[8]{}; int conv_S[8]{};   // valid frames / padded row stride per conv layer output
@@ -117,6 +119,9 @@ struct artalk_model {
     std::vector<std::pair<size_t, double>> dom_events;   // (event index of start, flops)
     std::vector<std::pair<int, size_t>> marks;          // (bucket of the interval ending here, event index)
     hipStream_t prof_stream = nullptr;
+    hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};   // extra branches of the AR body (run_chunk_body_graphs)
+    hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
+    int branches = 0;                 // 0 = automatic (2 for B >= 8), else forced 1/2/4
     hipStream_t own_stream = nullptr;   // used when the caller passes stream == NULL (graph capture needs a real stream)
     // graphs: one per active batch size
     std::map<int, hipGraphExec_t> graphs;
@@ -348,12 +353,13 @@ void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
         split = gemm_f16s_eligible(g);
     }
     // split-K for grids that would leave most CUs idle (small-M scale steps): S workgroups per output tile
-    if (g.batch == 1 && g.amode == 0 && m->ws.splitk && g.K >= 256) {
+    const Workspace& cw = m->view ? *m->view : m->ws;
+    if (g.batch == 1 && g.amode == 0 && cw.splitk && g.K >= 256) {
         const int tiles = gemm_tile_count(g, split);
         if (tiles < 192) {
             int S = std::min(std::min(g.K / 64, (384 + tiles - 1) / tiles), 16);
-            while (S > 1 && (int64_t)S * g.M * g.N > m->ws.splitk_floats) --S;
-            if (S > 1) { g.splitk = S; g.partial = m->ws.splitk; }
+            while (S > 1 && (int64_t)S * g.M * g.N > cw.splitk_floats) --S;
+            if (S > 1) { g.splitk = S; g.partial = cw.splitk; }
         }
     }
     const bool dominant = !m->in_body && g.M > 0 &&
@@ -483,7 +489,7 @@ void run_style(artalk_model* m, const float* style_motion, int B, hipStream_t s)
 // one VAE transformer stack (app/modules/bitwise_vae.py:149-157 / :183-191) on B sequences of T tokens, in place on ws.vh
 void run_vae_stack(artalk_model* m, const VAESide& S, int B, int T, int split, hipStream_t s) {
     const artalk_config& c = m->cfg;
-    Workspace& w = m->ws;
+    Workspace& w = m->view ? *m->view : m->ws;
     const int H = c.vae_hidden, M = B * T, F = H * 3 / 2;
     for (int i = 0; i < c.vae_depth; ++i) {
         const VAELayer& L = S.layers[i];
@@ -506,7 +512,7 @@ void run_vae_stack(artalk_model* m, const VAESide& S, int B, int T, int split, h
 // motion (already in ws.enc_in as normalised + pos-embedded rows) -> history bits, decoder features, prev tokens
 void run_reencode(artalk_model* m, int B, hipStream_t s) {
     const artalk_config& c = m->cfg;
-    Workspace& w = m->ws;
+    Workspace& w = m->view ? *m->view : m->ws;
     const int H = c.vae_hidden, T = 100;
     linear(m, w.enc_in, 128, m->enc.in_w, m->enc.in_b, w.vh, H, B * T, H, 128, ACT_LEAKY02, nullptr, s);
     run_vae_stack(m, m->enc, B, T, 0, s);
@@ -520,7 +526,7 @@ void run_reencode(artalk_model* m, int B, hipStream_t s) {
 void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
     struct BodyScope { artalk_model* m; BodyScope(artalk_model* x) : m(x) { m->in_body = true; } ~BodyScope() { m->in_body = false; } } scope(m);
     const artalk_config& c = m->cfg;
-    Workspace& w = m->ws;
+    Workspace& w = m->view ? *m->view : m->ws;
     const long ldada = m->ada_n;
     const long cache_l = (long)w.maxB * 2 * kNTok * 3 * kE;   // floats per layer
     // K/V of the 181 history tokens, once per layer (raw prev tokens, not modulated: app/transformer.py:68-70)
@@ -593,6 +599,99 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
     stage_mark(m, s, PB_VAE);
 }
 
+// A view of the workspace for clips [b0, ...): every per-clip buffer pointer advanced by b0 clips (compact step buffers get a
+// fixed 100-row region per clip so the two halves never overlap), its own split-K scratch.
+Workspace clip_view(const artalk_model* m, int b0, int branch) {
+    const artalk_config& c = m->cfg;
+    Workspace v = m->ws;
+    const long b = b0;
+    v.ada += b * kNTok * m->ada_n; v.style_cond += b * kE; v.prev_in += b * kNTok * kE;
+    v.cache += b * 2 * kNTok * 3 * kE;
+    v.x += b * 100 * kE; v.xmod += b * 100 * kE; v.attn_out += b * 100 * kE; v.ffn_h += b * 100 * 4 * kE;
+    v.logits += b * 100 * 2 * c.code_dim; v.fhat += b * 100 * c.code_dim; v.nextfeat += b * 100 * c.code_dim;
+    v.bits += b * kNTok * c.code_dim; v.hist_bits += b * kNTok * c.code_dim;
+    v.prev_fdec += b * 100 * c.code_dim; v.msfeat += b * 180 * c.code_dim; v.dec_x += b * 200 * c.code_dim;
+    const long H = c.vae_hidden;
+    v.vh += b * 200 * H; v.vln += b * 200 * H; v.vqkv += b * 200 * 3 * H; v.vatt += b * 200 * H; v.vmlp += b * 200 * H * 3 / 2;
+    v.dec_out += b * 200 * c.motion_dim; v.enc_in += b * 100 * 128; v.enc_out += b * 100 * c.code_dim;
+    v.motion_chunk += b * 100 * c.motion_dim;
+    v.splitk = m->ws.splitk_b[branch];
+    return v;
+}
+
+// The AR/VAE body of one chunk index for B clips.  The small scale steps leave most CUs idle, and clips are independent, so
+// for B >= 8 the batch is cut into two halves that run as parallel branches (stream s and m->side_stream; inside a capture this
+// becomes a fork/join in the hipGraph): one half's GPU-filling step overlaps the other half's latency-bound ones.
+int ensure_side_streams(artalk_model* m, int n);
+int run_chunk_body_split(artalk_model* m, int B, hipStream_t s) {
+    if (B < 8 || m->profiling == 2 || m->branches == 1) { run_chunk_body(m, B, s); return ARTALK_OK; }
+    if (int rc = ensure_side_streams(m, 1)) return rc;
+    const int B0 = (B + 1) / 2, B1 = B - B0;
+    Workspace v0 = clip_view(m, 0, 0), v1 = clip_view(m, B0, 1);
+    HIPCHK(m, hipEventRecord(m->fork_ev, s));
+    HIPCHK(m, hipStreamWaitEvent(m->side_stream[0], m->fork_ev, 0));
+    m->view = &v0; run_chunk_body(m, B0, s);
+    m->view = &v1; run_chunk_body(m, B1, m->side_stream[0]);
+    m->view = nullptr;
+    HIPCHK(m, hipEventRecord(m->join_ev[0], m->side_stream[0]));
+    HIPCHK(m, hipStreamWaitEvent(s, m->join_ev[0], 0));
+    return ARTALK_OK;
+}
+
+// Body of one chunk index through hipGraphs: the batch is cut into NS clip groups (1, 2 or 4), one graph per (active batch, group),
+// launched on NS streams so that they really run concurrently (a single captured graph with a fork/join ran almost serially).
+// HIP multiplexes streams onto a few hardware queues (4 by default): every extra stream a process creates can end up sharing a
+// queue with the caller's stream and serialise the branches, so side streams are created lazily and only as many as are used.
+int ensure_side_streams(artalk_model* m, int n) {
+    if (!m->fork_ev) HIPCHK(m, hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming));
+    for (int i = 0; i < n && i < 3; ++i) {
+        if (m->side_stream[i]) continue;
+        HIPCHK(m, hipStreamCreateWithFlags(&m->side_stream[i], hipStreamNonBlocking));
+        HIPCHK(m, hipEventCreateWithFlags(&m->join_ev[i], hipEventDisableTiming));
+    }
+    return ARTALK_OK;
+}
+int body_branches(const artalk_model* m, int B) {
+    // measured at batch 32: 1 branch 54.9 ms, 2 branches 49.5 ms, 4 branches 77-120 ms (queue sharing / contention)
+    const int want = m->branches > 0 ? m->branches : (B >= 8 ? 2 : 1);
+    return B >= 2 * want ? want : (B >= 8 ? 2 : 1);
+}
+int run_chunk_body_graphs(artalk_model* m, int B, hipStream_t s) {
+    const int NS = body_branches(m, B);
+    if (NS > 1) { if (int rc = ensure_side_streams(m, NS - 1)) return rc; }
+    Workspace views[4];
+    int b0[5];
+    for (int h = 0; h <= NS; ++h) b0[h] = (int)((long)B * h / NS);
+    hipStream_t st[4] = {s, m->side_stream[0], m->side_stream[1], m->side_stream[2]};
+    for (int h = 0; h < NS; ++h) {
+        views[h] = clip_view(m, b0[h], h);
+        const int key = (B * 8 + NS) * 4 + h;
+        if (m->graphs.find(key) != m->graphs.end()) continue;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIPCHK(m, hipStreamBeginCapture(st[h], hipStreamCaptureModeThreadLocal));
+        m->in_graph_body = true;
+        m->view = NS > 1 ? &views[h] : nullptr;
+        run_chunk_body(m, b0[h + 1] - b0[h], st[h]);
+        m->view = nullptr;
+        m->in_graph_body = false;
+        HIPCHK(m, hipStreamEndCapture(st[h], &graph));
+        HIPCHK(m, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        m->graphs.emplace(key, exec);
+    }
+    if (NS > 1) {
+        HIPCHK(m, hipEventRecord(m->fork_ev, s));
+        for (int h = 1; h < NS; ++h) HIPCHK(m, hipStreamWaitEvent(st[h], m->fork_ev, 0));
+    }
+    for (int h = 0; h < NS; ++h) HIPCHK(m, hipGraphLaunch(m->graphs[(B * 8 + NS) * 4 + h], st[h]));
+    for (int h = 1; h < NS; ++h) {
+        HIPCHK(m, hipEventRecord(m->join_ev[h - 1], st[h]));
+        HIPCHK(m, hipStreamWaitEvent(s, m->join_ev[h - 1], 0));
+    }
+    return ARTALK_OK;
+}
+
 int reserve(artalk_model* m, int maxB, int maxC) {
     const artalk_config& c = m->cfg;
     if (maxB <= m->ws.maxB && maxC <= m->ws.maxC) return ARTALK_OK;
@@ -622,7 +721,8 @@ int reserve(artalk_model* m, int maxB, int maxC) {
     w.cache = F((int64_t)c.ar_depth * maxB * 2 * kNTok * 3 * kE);
     w.x = F((int64_t)maxB * 100 * kE); w.xmod = F((int64_t)maxB * 100 * kE); w.attn_out = F((int64_t)maxB * 100 * kE);
     w.ffn_h = F((int64_t)maxB * 100 * 4 * kE); w.logits = F((int64_t)maxB * 100 * 2 * c.code_dim);
-    w.splitk_floats = (int64_t)8 << 20; w.splitk = F(w.splitk_floats);
+    w.splitk_floats = (int64_t)8 << 20; w.splitk = F(w.splitk_floats); w.splitk_b[0] = w.splitk;
+    for (int i = 1; i < 4; ++i) w.splitk_b[i] = F(w.splitk_floats);
     w.fhat = F((int64_t)maxB * 100 * c.code_dim); w.nextfeat = F((int64_t)maxB * 100 * c.code_dim);
     w.bits = dalloc_in<uint8_t>(m->ws_allocs, (int64_t)maxB * kNTok * c.code_dim);
     w.hist_bits = dalloc_in<uint8_t>(m->ws_allocs, (int64_t)maxB * kNTok * c.code_dim);
@@ -677,7 +777,6 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
     }
     for (int i = 0; i < 5; ++i) { m->pn[i] = c.patch_nums[i]; m->off[i + 1] = m->off[i] + c.patch_nums[i]; }
     init_ms_tables();
-    if (hipStreamCreate(&m->own_stream) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete m; return ARTALK_EHIP; }
     const int rc = build_registry(m);
     if (rc != ARTALK_OK) { g_create_error = m->err; artalk_destroy(m); return rc; }
     *out = m;
@@ -691,6 +790,11 @@ void artalk_destroy(artalk_model* m) {
     for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+    for (int i = 0; i < 3; ++i) {
+        if (m->side_stream[i]) (void)hipStreamDestroy(m->side_stream[i]);
+        if (m->join_ev[i]) (void)hipEventDestroy(m->join_ev[i]);
+    }
+    if (m->fork_ev) (void)hipEventDestroy(m->fork_ev);
     for (void* p : m->allocs) if (p) (void)hipFree(p);
     for (void* p : m->ws_allocs) if (p) (void)hipFree(p);
     delete m;
@@ -842,7 +946,13 @@ int artalk_set_precision(artalk_model* m, int mode) {
     }
     return ARTALK_OK;
 }
-int artalk_set_graphs(artalk_model* m, int enable) { if (!m) return ARTALK_EINVAL; m->use_graphs = enable != 0; return ARTALK_OK; }
+int artalk_set_graphs(artalk_model* m, int enable) {
+    if (!m) return ARTALK_EINVAL;
+    m->use_graphs = (enable & 0xff) != 0;
+    const int br = (enable >> 8) & 0xff;          // tuning: enable | (branches << 8) forces 1 / 2 / 4 concurrent clip groups
+    if (br == 0 || br == 1 || br == 2 || br == 4) m->branches = br; else return ARTALK_EINVAL;
+    return ARTALK_OK;
+}
 
 int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_stride, const int64_t* n_chunks, int B,
                  const float* style_motion_dev, const uint8_t* has_style, float* out_motion_dev, int64_t out_clip_stride,
@@ -850,6 +960,7 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
     if (!m || !audio_dev || !n_chunks || !out_motion_dev || B <= 0) return ARTALK_EINVAL;
     if (!m->finalized) return fail(m, ARTALK_ESTATE, "artalk_infer before artalk_finalize_weights");
     (void)hipSetDevice(m->device);
+    if (!stream && !m->own_stream) HIPCHK(m, hipStreamCreate(&m->own_stream));
     hipStream_t s = stream ? (hipStream_t)stream : m->own_stream;
     const artalk_config& c = m->cfg;
     int64_t C = 0, maxch = n_chunks[0];
@@ -897,23 +1008,10 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
                ACT_NONE, nullptr, s, m->precision == 1 ? LF_A_P8 : 0);
         stage_mark(m, s, PB_ADA);
         if (graphs) {
-            auto it = m->graphs.find(Bn);
-            if (it == m->graphs.end()) {
-                hipGraph_t graph = nullptr;
-                hipGraphExec_t exec = nullptr;
-                HIPCHK(m, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                m->in_graph_body = true;
-                run_chunk_body(m, Bn, s);
-                m->in_graph_body = false;
-                HIPCHK(m, hipStreamEndCapture(s, &graph));
-                HIPCHK(m, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-                (void)hipGraphDestroy(graph);
-                it = m->graphs.emplace(Bn, exec).first;
-            }
-            HIPCHK(m, hipGraphLaunch(it->second, s));
+            if (int brc = run_chunk_body_graphs(m, Bn, s)) return brc;
             stage_mark(m, s, PB_AR);   // light profiling: the whole captured body (AR steps + VAE) is charged to the AR bucket
         } else {
-            run_chunk_body(m, Bn, s);
+            if (int brc = run_chunk_body_split(m, Bn, s)) return brc;
         }
         const size_t mrow = (size_t)100 * c.motion_dim * 4;
         HIPCHK(m, hipMemcpy2DAsync(out_motion_dev + j * 100 * c.motion_dim, (size_t)out_clip_stride * 4, w.motion_chunk, mrow, mrow, Bn,
@@ -938,6 +1036,7 @@ int artalk_stream_begin(artalk_model* m, int B, const float* style_motion_dev, c
     if (!m || B <= 0) return ARTALK_EINVAL;
     if (!m->finalized) return fail(m, ARTALK_ESTATE, "artalk_stream_begin before artalk_finalize_weights");
     (void)hipSetDevice(m->device);
+    if (!stream && !m->own_stream) HIPCHK(m, hipStreamCreate(&m->own_stream));
     hipStream_t s = stream ? (hipStream_t)stream : m->own_stream;
     if (B > m->ws.maxB || B > m->ws.maxC) { if (int rc = reserve(m, B, B)) return rc; }
     Workspace& w = m->ws;
@@ -962,6 +1061,7 @@ int artalk_stream_chunk(artalk_model* m, const float* audio_dev, int64_t chunk_s
     if (!m || !audio_dev || !out_motion_dev) return ARTALK_EINVAL;
     if (m->stream_B <= 0) return fail(m, ARTALK_ESTATE, "artalk_stream_chunk before artalk_stream_begin");
     (void)hipSetDevice(m->device);
+    if (!stream && !m->own_stream) HIPCHK(m, hipStreamCreate(&m->own_stream));
     hipStream_t s = stream ? (hipStream_t)stream : m->own_stream;
     const int B = m->stream_B;
     Workspace& w = m->ws;
@@ -975,22 +1075,9 @@ int artalk_stream_chunk(artalk_model* m, const float* audio_dev, int64_t chunk_s
     linear(m, w.silu_cond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, B * kNTok, m->ada_n, kCond, ACT_NONE, nullptr, s,
            m->precision == 1 ? LF_A_P8 : 0);
     if (m->use_graphs) {
-        auto it = m->graphs.find(B);
-        if (it == m->graphs.end()) {
-            hipGraph_t graph = nullptr;
-            hipGraphExec_t exec = nullptr;
-            HIPCHK(m, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            m->in_graph_body = true;
-            run_chunk_body(m, B, s);
-            m->in_graph_body = false;
-            HIPCHK(m, hipStreamEndCapture(s, &graph));
-            HIPCHK(m, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(graph);
-            it = m->graphs.emplace(B, exec).first;
-        }
-        HIPCHK(m, hipGraphLaunch(it->second, s));
+        if (int brc = run_chunk_body_graphs(m, B, s)) return brc;
     } else {
-        run_chunk_body(m, B, s);
+        if (int brc = run_chunk_body_split(m, B, s)) return brc;
     }
     m->profiling = saved;
     const size_t mrow = (size_t)100 * m->cfg.motion_dim * 4;

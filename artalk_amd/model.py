@@ -154,8 +154,9 @@ class BitwiseARModel:
         if rc != capi.OK:
             raise ValueError("precision mode must be 'f32' or 'f16x3'")
 
-    def set_graphs(self, on: bool):
-        capi.lib().artalk_set_graphs(self._h, int(bool(on)))
+    def set_graphs(self, on: bool, branches: int = 0):
+        """hipGraph replay of the AR/VAE body; ``branches`` (0 auto, 1, 2, 4) = concurrent clip groups."""
+        capi.lib().artalk_set_graphs(self._h, int(bool(on)) | (int(branches) << 8))
 
     def get_profile(self):
         out = (C.c_double * 10)()

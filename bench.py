@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--config", default="full")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
                     help="GEMM arithmetic: exact fp32 MFMA, or fp16 operand-split MFMA with fp32-class accuracy")
+    ap.add_argument("--branches", type=int, default=0, help="concurrent clip groups of the AR body (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=12)
     args = ap.parse_args()
@@ -104,6 +105,7 @@ def main():
     model = BitwiseARModel(cfg).eval().to(dev)
     model.load_state_dict(sd, strict=True)
     model.set_precision(args.precision)
+    model.set_graphs(True, args.branches)
     t_load = time.time() - t0
     log(f"rank {rank}: weights generated + loaded in {t_load:.1f} s")
 

@@ -123,7 +123,8 @@ int artalk_get_profile(artalk_model* m, double* out, int n);
  * fp16 values (22 significand bits), three fp16 MFMA products accumulated in fp32 - fp32-class accuracy (parity tests run in
  * both modes) at 5.3x the matrix-core rate; the logit / code heads stay on the fp32 path in both modes. */
 int artalk_set_precision(artalk_model* m, int mode);
-/* Replay the AR/VAE part from hipGraphs captured per active-batch size (default 1 = on). */
+/* Replay the AR/VAE part from hipGraphs captured per active-batch size (default 1 = on).  The batch is cut into 1/2/4 clip
+ * groups whose graphs run concurrently on separate streams (automatic; enable | (groups << 8) forces a count, for tuning). */
 int artalk_set_graphs(artalk_model* m, int enable);
 
 /* ---- single-kernel entry points for the parity tests (device pointers, row-major f32) ---- */
