@@ -61,7 +61,8 @@ void launch_pack_split(const float* w, unsigned int* out, long n, hipStream_t s)
     hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, w, out, n);
 }
 
-template <int BM, int BN, int WM, int WN, int APK, int TAG>
+// AMODE 1: grouped positional-conv window gather (see gemm_f32.hip), grid.z = group, fp32 A only.
+template <int BM, int BN, int WM, int WN, int APK, int TAG, int AMODE = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
     constexpr int BK = 32;
     constexpr int ROWB = 144;                      // bytes per LDS row: 64 (hi) + 64 (lo) + 16 pad
@@ -87,8 +88,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
         tm = first_m + (in_g - tn * gsz);
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const float* __restrict__ A = g.A;
-    const unsigned int* __restrict__ Wp = g.Wp;
+    const int z = blockIdx.z;
+    const float* __restrict__ A = g.A + z * g.sA;
+    const unsigned int* __restrict__ Wp = g.Wp + z * g.sW;
 
     u32x4 ra[A_LD];   // fp32 bits (APK=0: split while staging) or packed (hi | lo<<16) words (APK=1: producer already split)
     u32x4 rb[B_LD];
@@ -100,7 +102,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
         for (int i = 0; i < A_LD; ++i) {
             const int gm = m0 + lrow + i * 32;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (gm < g.M) v = *reinterpret_cast<const u32x4*>(A + (long)gm * g.lda + k);
+            if (gm < g.M) {
+                if (AMODE == 0) {
+                    v = *reinterpret_cast<const u32x4*>(A + (long)gm * g.lda + k);
+                } else {
+                    const int c = gm / g.pc_tstride, t = gm - c * g.pc_tstride;
+                    const int tap = k / g.pc_cin, ci = k - tap * g.pc_cin;
+                    const int ts = t + tap - g.pc_pad;
+                    if (ts >= 0 && ts < g.pc_T) v = *reinterpret_cast<const u32x4*>(A + ((long)c * g.pc_tstride + ts) * g.lda + ci);
+                }
+            }
             ra[i] = v;
         }
 #pragma unroll
@@ -193,9 +204,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
         }
         return;
     }
-    const float* __restrict__ bias = g.bias;
-    float* __restrict__ C = g.C;
-    const float* R = g.R;
+    const float* __restrict__ bias = g.bias ? g.bias + z * g.sBias : nullptr;
+    float* __restrict__ C = g.C + z * g.sC;
+    const float* R = g.R ? g.R + z * g.sR : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (BN / WN) + j * 32 + r;
@@ -432,7 +443,9 @@ template <int BM, int BN, int WM, int WN>
 static void launch_f16s_cfg(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     const size_t lds = 2 * (BM + BN) * 144;
-    if (g.a_packed) {
+    if (g.amode == 1) {
+        hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 0, 0, 1>), dim3(tiles, 1, g.batch), dim3(256), lds, s, g);
+    } else if (g.a_packed) {
         if (g.graph_tag) hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 1, 1>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
         else hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 1, 0>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
     } else {
@@ -444,6 +457,7 @@ static void launch_f16s_cfg(const GemmArgs& g, hipStream_t s) {
 // 0: 128x128 (dominant kernel of the split mode), 1: 64x64
 int gemm_f16s_config(const GemmArgs& g) {
     if (g.force_cfg >= 0) return g.force_cfg;
+    if (g.amode == 1) return 1;   // N = 64 per group
     // 64x64 tiles (4-5 workgroups/CU) beat 128x128 (2/CU) until the grid is several waves deep: M=3200,N=3072,K=768 runs at
     // 210 vs 135 TF/s (profiles/r01_gemm_f16s_bench.log)
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
@@ -451,7 +465,8 @@ int gemm_f16s_config(const GemmArgs& g) {
 }
 
 bool gemm_f16s_eligible(const GemmArgs& g) {
-    return g.Wp != nullptr && g.amode == 0 && g.batch == 1 && g.K % 32 == 0;
+    if (g.amode == 1) return g.Wp != nullptr && !g.a_packed && g.splitk == 1 && g.K % 32 == 0 && g.pc_cin % 32 == 0;
+    return g.Wp != nullptr && g.batch == 1 && g.K % 32 == 0;
 }
 
 void launch_gemm_f16s(const GemmArgs& g, hipStream_t s) {
