@@ -82,7 +82,7 @@ void launch_ar_begin(const float* style_cond, const float* lvlpos, float* x0, fl
 // ------------------------------------------------------------------------------------------------
 // level p: logits rows b*pn+i -> bits; f_hat += up(h_p); nextfeat[b, i', :] = area(f_hat -> pn[p+1])
 __global__ __launch_bounds__(256) void ar_bits_kernel(const float* __restrict__ logits, uint8_t* __restrict__ bits,
-                                                      float* __restrict__ fhat, float* __restrict__ nextfeat, int p) {
+                                                      float* __restrict__ fhat, float* __restrict__ nextfeat, int p, int* __restrict__ status) {
     __shared__ float hs[T100 * CD];
     __shared__ float fs[T100 * CD];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -91,6 +91,8 @@ __global__ __launch_bounds__(256) void ar_bits_kernel(const float* __restrict__ 
         const int i = idx / CD, c = idx % CD;
         const float* l = logits + ((long)b * pn + i) * (2 * CD) + 2 * c;
         const int bit = l[1] > l[0];                       // argmax over the pair, ties -> 0
+        // a NaN/Inf logit would be laundered into a 0 bit by the comparison: report it (fp16 overflow in f16x3 mode, bad weights)
+        if (status && !(isfinite(l[0]) && isfinite(l[1]))) atomicOr(status, 1);
         bits[((long)b * 181 + off + i) * CD + c] = (uint8_t)bit;
         hs[idx] = bit ? c_hq : -c_hq;
     }
@@ -108,8 +110,8 @@ __global__ __launch_bounds__(256) void ar_bits_kernel(const float* __restrict__ 
     for (int idx = tid; idx < pn2 * CD; idx += 256)
         nextfeat[(long)b * pn2 * CD + idx] = area_pool(fs, pn2, idx / CD, idx % CD);
 }
-void launch_ar_bits_next(const float* logits, uint8_t* bits, float* fhat, float* nextfeat, int B, int level, hipStream_t s) {
-    hipLaunchKernelGGL(ar_bits_kernel, dim3(B), dim3(256), 0, s, logits, bits, fhat, nextfeat, level);
+void launch_ar_bits_next(const float* logits, uint8_t* bits, float* fhat, float* nextfeat, int B, int level, hipStream_t s, int* status) {
+    hipLaunchKernelGGL(ar_bits_kernel, dim3(B), dim3(256), 0, s, logits, bits, fhat, nextfeat, level, status);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -168,7 +170,7 @@ void launch_dec_input(const float* prev_fdec, const float* fhat, const uint8_t* 
 __global__ __launch_bounds__(256) void dec_finish_kernel(const float* __restrict__ dec, const float* __restrict__ mean,
                                                          const float* __restrict__ stdv, const float* __restrict__ epos,
                                                          float* __restrict__ out, long out_bstride, int chunk,
-                                                         float* __restrict__ E, int MD, int EK) {
+                                                         float* __restrict__ E, int MD, int EK, int* __restrict__ status) {
     const int b = blockIdx.x;
     for (int idx = threadIdx.x; idx < T100 * EK; idx += 256) {
         const int t = idx / EK, j = idx % EK;
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(256) void dec_finish_kernel(const float* __restrict
         if (j < MD) {
             const float d = dec[((long)b * 2 * T100 + T100 + t) * MD + j];
             const float m = d * stdv[j] + mean[j];
+            if (status && !isfinite(m)) atomicOr(status, 4);
             out[(long)b * out_bstride + ((long)chunk * T100 + t) * MD + j] = m;
             e = (m - mean[j]) / stdv[j] + epos[t * MD + j];
         }
@@ -183,8 +186,8 @@ __global__ __launch_bounds__(256) void dec_finish_kernel(const float* __restrict
     }
 }
 void launch_dec_finish(const float* dec, const float* mean, const float* stdv, const float* epos, float* out,
-                       long out_bstride, int chunk, float* E, int B, hipStream_t s) {
-    hipLaunchKernelGGL(dec_finish_kernel, dim3(B), dim3(256), 0, s, dec, mean, stdv, epos, out, out_bstride, chunk, E, 106, 128);
+                       long out_bstride, int chunk, float* E, int B, hipStream_t s, int* status) {
+    hipLaunchKernelGGL(dec_finish_kernel, dim3(B), dim3(256), 0, s, dec, mean, stdv, epos, out, out_bstride, chunk, E, 106, 128, status);
 }
 
 __global__ __launch_bounds__(256) void enc_input_zero_kernel(const float* __restrict__ mean, const float* __restrict__ stdv,
@@ -202,7 +205,7 @@ void launch_enc_input_zero(const float* mean, const float* stdv, const float* ep
 // ------------------------------------------------------------------------------------------------
 // One workgroup per clip.  Sequential over the 5 scales (each needs the residual left by the previous one).
 __global__ __launch_bounds__(256) void bsq_history_kernel(const float* __restrict__ enc_out, uint8_t* __restrict__ hist_bits,
-                                                          float* __restrict__ prev_fdec, float* __restrict__ msfeat) {
+                                                          float* __restrict__ prev_fdec, float* __restrict__ msfeat, int* __restrict__ status) {
     __shared__ float resid[T100 * CD];
     __shared__ float fms[T100 * CD];     // sum of up(h_p), the feature recurrence from bits
     __shared__ float qs[T100 * CD];      // quantised values q = z + (zhat - z) of this scale
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(256) void bsq_history_kernel(const float* __restric
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int idx = tid; idx < T100 * CD; idx += 256) {
         resid[idx] = enc_out[(long)b * T100 * CD + idx];
+        if (status && !isfinite(resid[idx])) atomicOr(status, 2);
         fms[idx] = 0.f;
     }
     __syncthreads();
@@ -254,8 +258,8 @@ __global__ __launch_bounds__(256) void bsq_history_kernel(const float* __restric
         __syncthreads();
     }
 }
-void launch_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fdec, float* msfeat, int B, hipStream_t s) {
-    hipLaunchKernelGGL(bsq_history_kernel, dim3(B), dim3(256), 0, s, enc_out, hist_bits, prev_fdec, msfeat);
+void launch_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fdec, float* msfeat, int B, hipStream_t s, int* status) {
+    hipLaunchKernelGGL(bsq_history_kernel, dim3(B), dim3(256), 0, s, enc_out, hist_bits, prev_fdec, msfeat, status);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -66,6 +66,7 @@ struct Workspace {
     float* splitk = nullptr; int64_t splitk_floats = 0;   // partial sums of split-K GEMMs
     float* splitk_b[4] = {nullptr, nullptr, nullptr, nullptr};   // one scratch per concurrent branch of the AR body (splitk_b[0] == splitk)
     uint8_t *bits = nullptr, *hist_bits = nullptr, *has_style = nullptr;
+    int* status = nullptr;           // device word: bit 0 non-finite logit, bit 1 non-finite re-encoder output (see artalk_get_status)
     // VAE
     float *prev_fdec = nullptr, *msfeat = nullptr, *dec_x = nullptr, *vh = nullptr, *vln = nullptr, *vqkv = nullptr;
     float *vatt = nullptr, *vmlp = nullptr, *dec_out = nullptr, *enc_in = nullptr, *enc_out = nullptr, *motion_chunk = nullptr;
@@ -517,7 +518,7 @@ void run_reencode(artalk_model* m, int B, hipStream_t s) {
     linear(m, w.enc_in, 128, m->enc.in_w, m->enc.in_b, w.vh, H, B * T, H, 128, ACT_LEAKY02, nullptr, s);
     run_vae_stack(m, m->enc, B, T, 0, s);
     linear(m, w.vh, H, m->enc.out_w, m->enc.out_b, w.enc_out, c.code_dim, B * T, c.code_dim, H, ACT_NONE, nullptr, s, LF_EXACT);
-    launch_bsq_history(w.enc_out, w.hist_bits, w.prev_fdec, w.msfeat, B, s);
+    launch_bsq_history(w.enc_out, w.hist_bits, w.prev_fdec, w.msfeat, B, s, w.status);
     launch_vq_embed(w.msfeat, kNTok - 1, m->vq_w, m->vq_b, m->prev_lvl_pos + kE, w.prev_in, kNTok, 1, w.style_cond,
                     m->prev_lvl_pos, B, s);
 }
@@ -581,7 +582,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
         nh.M = M; nh.D = kE; nh.eps = 1e-6f;
         launch_layernorm(nh, s);
         linear(m, w.xmod, kE, m->logits_w, m->logits_b, w.logits, 2 * c.code_dim, M, 2 * c.code_dim, kE, ACT_NONE, nullptr, s, LF_EXACT);
-        launch_ar_bits_next(w.logits, w.bits, w.fhat, w.nextfeat, B, p, s);
+        launch_ar_bits_next(w.logits, w.bits, w.fhat, w.nextfeat, B, p, s, w.status);
         if (p + 1 < c.n_levels)
             launch_vq_embed(w.nextfeat, m->pn[p + 1], m->vq_w, m->vq_b, m->lvl_pos + (long)m->off[p + 1] * kE, w.x, m->pn[p + 1], 0,
                             nullptr, nullptr, B, s);
@@ -593,7 +594,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
     linear(m, w.dec_x, c.code_dim, m->dec.in_w, m->dec.in_b, w.vh, H, B * 200, H, c.code_dim, ACT_LEAKY02, nullptr, s);
     run_vae_stack(m, m->dec, B, 200, 100, s);
     linear(m, w.vh, H, m->dec.out_w, m->dec.out_b, w.dec_out, c.motion_dim, B * 200, c.motion_dim, H, ACT_NONE, nullptr, s);
-    launch_dec_finish(w.dec_out, m->vae_mean, m->vae_std, m->enc_pos, w.motion_chunk, 100L * c.motion_dim, 0, w.enc_in, B, s);
+    launch_dec_finish(w.dec_out, m->vae_mean, m->vae_std, m->enc_pos, w.motion_chunk, 100L * c.motion_dim, 0, w.enc_in, B, s, w.status);
     // ---- re-encode the generated motion into the next history (app/models.py:111-114) ----
     run_reencode(m, B, s);
     stage_mark(m, s, PB_VAE);
@@ -727,6 +728,7 @@ int reserve(artalk_model* m, int maxB, int maxC) {
     w.bits = dalloc_in<uint8_t>(m->ws_allocs, (int64_t)maxB * kNTok * c.code_dim);
     w.hist_bits = dalloc_in<uint8_t>(m->ws_allocs, (int64_t)maxB * kNTok * c.code_dim);
     w.has_style = dalloc_in<uint8_t>(m->ws_allocs, maxB);
+    w.status = dalloc_in<int>(m->ws_allocs, 4);
     w.prev_fdec = F((int64_t)maxB * 100 * c.code_dim); w.msfeat = F((int64_t)maxB * 180 * c.code_dim);
     const int H = c.vae_hidden;
     w.dec_x = F((int64_t)maxB * 200 * c.code_dim); w.vh = F((int64_t)maxB * 200 * H); w.vln = F((int64_t)maxB * 200 * H);
@@ -985,6 +987,7 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
     if (style_motion_dev && has_style) HIPCHK(m, hipMemcpyAsync(w.has_style, has_style, B, hipMemcpyHostToDevice, s));
     HIPCHK(m, hipStreamSynchronize(s));   // src/has_style are stack/heap temporaries of this call
     m->stream_B = 0;   // the batch call reuses the workspace that holds the streaming history
+    HIPCHK(m, hipMemsetAsync(w.status, 0, 4 * sizeof(int), s));
     m->ev_used = 0; m->dom_events.clear(); m->marks.clear(); m->prof_stream = s;
     stage_mark(m, s, PB_OTHER);
     run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s);
@@ -1083,6 +1086,21 @@ int artalk_stream_chunk(artalk_model* m, const float* audio_dev, int64_t chunk_s
     const size_t mrow = (size_t)100 * m->cfg.motion_dim * 4;
     HIPCHK(m, hipMemcpy2DAsync(out_motion_dev, (size_t)out_stride * 4, w.motion_chunk, mrow, mrow, B, hipMemcpyDeviceToDevice, s));
     HIPCHK(m, hipGetLastError());
+    return ARTALK_OK;
+}
+
+// Numerical health of the calls since the last artalk_infer started (synchronises `stream`): bit 0 = a logit was NaN/Inf (the
+// pairwise argmax would have turned it into a 0 bit), bit 1 = a re-encoder output was NaN/Inf.  Non-zero in f16x3 mode means an
+// activation left fp16's range: redo the call in f32 mode.
+int artalk_get_status(artalk_model* m, int* flags, void* stream) {
+    if (!m || !flags) return ARTALK_EINVAL;
+    if (!m->ws.status) { *flags = 0; return ARTALK_OK; }
+    (void)hipSetDevice(m->device);
+    hipStream_t s = stream ? (hipStream_t)stream : m->own_stream;
+    int h = 0;
+    HIPCHK(m, hipMemcpyAsync(&h, m->ws.status, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(m, hipStreamSynchronize(s));
+    *flags = h;
     return ARTALK_OK;
 }
 

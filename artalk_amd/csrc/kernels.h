@@ -101,7 +101,8 @@ void launch_pool_silu(const float* X, int x_tstride, int T, float* Y, int n_chun
 
 // ---- AR / VAE glue ----
 // level p: logits [B*pn, 64] -> bits[b, off..off+pn, 32]; fhat[b] += up(h_p); nextfeat[b, :pn[p+1], 32] = area(fhat) (p < 4)
-void launch_ar_bits_next(const float* logits, uint8_t* bits, float* fhat, float* nextfeat, int B, int level, hipStream_t s);
+void launch_ar_bits_next(const float* logits, uint8_t* bits, float* fhat, float* nextfeat, int B, int level, hipStream_t s,
+                         int* status = nullptr);   // status |= 1 if a logit is not finite
 // X[b*xrows + xoff + i, :] = We*feat[b,i,:] + be + pos[i,:] (i < n); if style_cond: X[b*xrows, :] = style_cond[b] + pos0
 void launch_vq_embed(const float* feat, int n, const float* We, const float* be, const float* pos, float* X, int xrows,
                      int xoff, const float* style_cond, const float* pos0, int B, hipStream_t s);
@@ -112,11 +113,12 @@ void launch_dec_input(const float* prev_fdec, const float* fhat, const uint8_t* 
                       int B, hipStream_t s);
 // motion = dec*std+mean (2nd half rows) -> out[b, chunk*100 + t, :106]; enc_in = (motion-mean)/std + epos[t] -> E [B*100,128] (cols>=106 zero)
 void launch_dec_finish(const float* dec /*[B*200,106]*/, const float* mean, const float* stdv, const float* epos,
-                       float* out, long out_bstride, int chunk, float* E, int B, hipStream_t s);
+                       float* out, long out_bstride, int chunk, float* E, int B, hipStream_t s, int* status = nullptr);   // status |= 4: non-finite code
 // zero motion encoder input (initial history): E[b*100+t] = (0-mean)/std + epos[t]
 void launch_enc_input_zero(const float* mean, const float* stdv, const float* epos, float* E, int B, hipStream_t s);
 // multi-scale BSQ of enc_out [B*100,32] -> hist bits [B,181,32], prev_fdec [B,100,32], ms feats [B,180,32]
-void launch_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fdec, float* msfeat, int B, hipStream_t s);
+void launch_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fdec, float* msfeat, int B, hipStream_t s,
+                        int* status = nullptr);    // status |= 2 if an encoder output is not finite
 // style: X[b*50+t, 0:128] = (m - mean)/std (cols >= 106 zero)
 void launch_style_input(const float* motion, const float* mean, const float* stdv, float* X, int B, hipStream_t s);
 // style_cond[b] = has_style[b] ? 1.1*(Ws*mean_t(feat[b]) + bs) - 0.1*null : null

@@ -59,6 +59,8 @@ class BitwiseARModel:
         self._h = None
         self._loaded = False
         self._reserved = (0, 0)
+        self.check_finite = True   # f16x3 mode: verify the result is finite (one small reduction + sync per call)
+        self._precision = "f16x3"   # default GEMM arithmetic (set_precision); applied when the weights are loaded
         self._stream = None      # dedicated HIP stream (hipGraph capture is not allowed on the legacy default stream)
         self.last_aux = {}
 
@@ -128,6 +130,7 @@ class BitwiseARModel:
         if errors:
             raise RuntimeError("Error(s) in loading state_dict for BitwiseARModel:\n\t" + "\n\t".join(errors[:12]))
         self._loaded = True
+        self.set_precision(self._precision)
         return self
 
     def reserve(self, max_batch: int, max_total_chunks: int):
@@ -136,6 +139,12 @@ class BitwiseARModel:
         if rc != capi.OK:
             raise RuntimeError("artalk_reserve failed: " + self._err())
         self._reserved = (int(max_batch), int(max_total_chunks))
+
+    def _status(self) -> int:
+        """Health flags of the last call (artalk_get_status): non-zero = a NaN/Inf reached a decision."""
+        f = C.c_int(0)
+        capi.lib().artalk_get_status(self._h, C.byref(f), C.c_void_p(self._stream.cuda_stream) if self._stream is not None else None)
+        return int(f.value)
 
     def workspace_bytes(self):
         return int(capi.lib().artalk_workspace_bytes(self._h))
@@ -148,11 +157,17 @@ class BitwiseARModel:
         capi.lib().artalk_set_profiling(self._h, int(level))
 
     def set_precision(self, mode):
-        """'f32' / 0: exact fp32 MFMA (default); 'f16x3' / 1: fp16 operand-split GEMMs with fp32-class accuracy."""
-        mode = {"f32": 0, "f16x3": 1}.get(mode, mode)
-        rc = capi.lib().artalk_set_precision(self._h, int(mode))
-        if rc != capi.OK:
+        """'f16x3' / 1 (default): fp16 operand-split MFMA GEMMs, fp32-class accuracy (more accurate than the fp32 MFMA chain on
+        every fixture) but operands must stay below fp16's 65504; 'f32' / 0: exact fp32 MFMA.  ``inference_batch`` falls back to
+        'f32' for a call whose f16x3 result is not finite (an fp16 overflow in some activation)."""
+        code = {"f32": 0, "f16x3": 1}.get(mode, mode)
+        if code not in (0, 1):
             raise ValueError("precision mode must be 'f32' or 'f16x3'")
+        self._precision = "f16x3" if code == 1 else "f32"
+        if self._h is not None and self._loaded:
+            rc = capi.lib().artalk_set_precision(self._h, int(code))
+            if rc != capi.OK:
+                raise ValueError("precision mode must be 'f32' or 'f16x3'")
 
     def set_graphs(self, on: bool, branches: int = 0):
         """hipGraph replay of the AR/VAE body; ``branches`` (0 auto, 1, 2, 4) = concurrent clip groups."""
@@ -276,7 +291,7 @@ class BitwiseARModel:
                         assert tuple(s.shape) == (self.cfg.style_len, self.cfg.motion_dim), f"Invalid style_motion shape: {tuple(s.shape)}."
                         style_t[pos] = s.to(device=dev, dtype=torch.float32)
                         has[pos] = 1
-            out = torch.empty(B, maxch * 100, self.cfg.motion_dim, dtype=torch.float32, device=dev)
+            out = torch.zeros(B, maxch * 100, self.cfg.motion_dim, dtype=torch.float32, device=dev)   # zeros: rows past a clip's last chunk
             bits = hist = w2v = None
             if return_aux:
                 bits = torch.zeros(B, maxch, 181, 32, dtype=torch.uint8, device=dev)
@@ -296,6 +311,15 @@ class BitwiseARModel:
                     t.record_stream(self._stream)
             if rc != capi.OK:
                 raise RuntimeError("artalk_infer failed ({}): {}".format(rc, self._err()))
+            if self._precision == "f16x3" and self.check_finite and self._status() != 0:
+                # an activation left fp16's range: redo this call with exact fp32 MFMA GEMMs (never silently return NaNs)
+                import warnings
+                warnings.warn("artalk_amd: non-finite result in f16x3 mode, re-running this call in f32 mode")
+                self.set_precision("f32")
+                try:
+                    return self.inference_batch(audios, style_motions, return_aux)
+                finally:
+                    self.set_precision("f16x3")
             results: List[Optional[torch.Tensor]] = [None] * B
             for pos, i in enumerate(order):
                 results[i] = out[pos, :seq[i]]                               # truncate, app/models.py:115

@@ -106,6 +106,11 @@ int artalk_flame_verts(artalk_flame* f, const float* betas_dev, const float* ful
 void artalk_flame_destroy(artalk_flame* f);
 const char* artalk_flame_last_error(const artalk_flame* f);
 
+/* Numerical health of the last artalk_infer (synchronises `stream`): bit 0 a logit was NaN/Inf (the pairwise argmax of
+ * app/models.py:104 would silently turn it into a 0 bit), bit 1 a re-encoder output was NaN/Inf, bit 2 a FLAME code was NaN/Inf.  Non-zero in f16x3 mode means an
+ * activation left fp16's range: redo the call in f32 mode (the Python host does). */
+int artalk_get_status(artalk_model* m, int* flags, void* stream);
+
 /* Savitzky-Golay smoothing of inference.py:89-95 on the device: in/out [T][106] f32, T >= 9. */
 int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, void* stream);
 

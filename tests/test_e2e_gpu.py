@@ -130,6 +130,32 @@ def test_streaming_equals_batch_call():
         m.stream_chunk(torch.zeros(3, 64000))
 
 
+def test_f16x3_overflow_falls_back_to_f32():
+    """An activation beyond fp16's range makes the f16x3 result non-finite; the host re-runs the call in f32 mode instead of
+    returning NaNs.  Forced here with weights scaled so that a GEMM input exceeds 65504."""
+    import warnings
+    from artalk_amd.model import BitwiseARModel
+    from artalk_amd.synth import synth_audio
+    cfg, sd = get_state_dict("tiny")
+    big = dict(sd)
+    k = "audio_encoder.feature_projection.layer_norm.weight"       # LN output feeds the projection GEMM: 1e6 > 65504
+    big[k] = sd[k] * 1e6
+    kk = "audio_encoder.feature_projection.projection.weight"
+    big[kk] = sd[kk] * 1e-6                                          # keep the function the same in exact arithmetic
+    m = BitwiseARModel(cfg).eval().to("cuda")
+    m.load_state_dict(big, strict=True)
+    audio = torch.from_numpy(synth_audio(3, 4.0))
+    m.set_precision("f32")
+    want = m.inference_batch([audio])[0]
+    m.set_precision("f16x3")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = m.inference_batch([audio])[0]
+    assert any("re-running" in str(x.message) for x in w)
+    assert torch.isfinite(got).all() and torch.equal(got, want)
+    assert m._precision == "f16x3"
+
+
 def test_reference_call_surface():
     """BitwiseARModel.inference(batch) / ARTAvatarInferEngine.inference(audio) keep the reference's surface."""
     from artalk_amd.engine import ARTAvatarInferEngine
