@@ -804,6 +804,7 @@ void artalk_destroy(artalk_model* m) {
 
 int artalk_set_tensor(artalk_model* m, const char* key, const void* host_ptr, int dtype, int ndim, const int64_t* shape) {
     if (!m || !key || !host_ptr || !shape) return ARTALK_EINVAL;
+    if (m->finalized) return fail(m, ARTALK_ESTATE, "weights are final after artalk_finalize_weights (derived layouts and packed copies exist); create a new model");
     auto it = m->slots.find(key);
     if (it == m->slots.end()) return fail(m, ARTALK_EKEY, std::string("Unexpected key in state_dict: ") + key);
     Slot& s = it->second;

@@ -102,6 +102,9 @@ class BitwiseARModel:
         """``load_state_dict(ckpt, strict=True)`` of reference ``inference.py:28`` (814-entry manifest)."""
         assert strict, "only strict=True (what the reference uses) is supported"
         L = capi.lib()
+        if self._h is not None and self._loaded:      # reloading: derived layouts/packed copies belong to the old weights
+            L.artalk_destroy(self._h)
+            self._h, self._loaded, self._stream = None, False, None
         if self._h is None:
             h = C.c_void_p()
             cs = capi.config_struct(self.cfg)
