@@ -89,6 +89,7 @@ struct artalk_model {
     struct PackRange { const float* base; int64_t n; unsigned int* packed; };
     std::vector<PackRange> wranges;   // every weight allocation and its packed f16x3 copy (built at finalize)
     int precision = 0;                // 0: fp32 MFMA everywhere, 1: f16x3 split GEMMs (heads stay fp32)
+    int splitk_tiles = 192, splitk_target = 384;   // split-K when the grid has fewer tiles than splitk_tiles; aim at splitk_target workgroups
     int stream_B = 0;                 // streams opened by artalk_stream_begin (history lives in the workspace)
     Workspace* view = nullptr;        // workspace view (clip sub-range) the body launchers currently work on; null = m->ws
     bool sticky_error = false;        // set by internal consistency checks inside the launch sequence; reported by artalk_infer
@@ -357,8 +358,9 @@ void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
     const Workspace& cw = m->view ? *m->view : m->ws;
     if (g.batch == 1 && g.amode == 0 && cw.splitk && g.K >= 256) {
         const int tiles = gemm_tile_count(g, split);
-        if (tiles < 192) {
-            int S = std::min(std::min(g.K / 64, (384 + tiles - 1) / tiles), 16);
+        const int lim = m->splitk_tiles, tgt = m->splitk_target;
+        if (tiles < lim) {
+            int S = std::min(std::min(g.K / 64, (tgt + tiles - 1) / tiles), 16);
             while (S > 1 && (int64_t)S * g.M * g.N > cw.splitk_floats) --S;
             if (S > 1) { g.splitk = S; g.partial = cw.splitk; }
         }
@@ -954,6 +956,12 @@ int artalk_set_graphs(artalk_model* m, int enable) {
     m->use_graphs = (enable & 0xff) != 0;
     const int br = (enable >> 8) & 0xff;          // tuning: enable | (branches << 8) forces 1 / 2 / 4 concurrent clip groups
     if (br == 0 || br == 1 || br == 2 || br == 4) m->branches = br; else return ARTALK_EINVAL;
+    if ((enable >> 16) & 0xffff) {                // tuning: split-K thresholds, (tiles/16) << 16 | (target/16) << 24
+        m->splitk_tiles = ((enable >> 16) & 0xff) * 16; m->splitk_target = ((enable >> 24) & 0xff) * 16;
+    }
+    (void)hipSetDevice(m->device); (void)hipDeviceSynchronize();
+    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
+    m->graphs.clear();
     return ARTALK_OK;
 }
 

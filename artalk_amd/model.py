@@ -172,9 +172,10 @@ class BitwiseARModel:
             if rc != capi.OK:
                 raise ValueError("precision mode must be 'f32' or 'f16x3'")
 
-    def set_graphs(self, on: bool, branches: int = 0):
-        """hipGraph replay of the AR/VAE body; ``branches`` (0 auto, 1, 2, 4) = concurrent clip groups."""
-        capi.lib().artalk_set_graphs(self._h, int(bool(on)) | (int(branches) << 8))
+    def set_graphs(self, on: bool, branches: int = 0, splitk_tiles: int = 0, splitk_target: int = 0):
+        """hipGraph replay of the AR/VAE body; ``branches`` (0 auto, 1, 2, 4) = concurrent clip groups; the split-K thresholds are
+        tuning knobs (multiples of 16, 0 = keep)."""
+        capi.lib().artalk_set_graphs(self._h, int(bool(on)) | (int(branches) << 8) | ((splitk_tiles // 16) << 16) | ((splitk_target // 16) << 24))
 
     def get_profile(self):
         out = (C.c_double * 10)()

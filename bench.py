@@ -72,7 +72,9 @@ def main():
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
                     help="GEMM arithmetic: exact fp32 MFMA, or fp16 operand-split MFMA with fp32-class accuracy")
     ap.add_argument("--branches", type=int, default=0, help="concurrent clip groups of the AR body (0 = auto)")
+    ap.add_argument("--splitk", default="0,0", help="tuning: split-K tile threshold,target workgroups (0 = keep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra (untimed) f32-mode measurement")
     ap.add_argument("--cpu-clips", type=int, default=12)
     args = ap.parse_args()
 
@@ -105,7 +107,8 @@ def main():
     model = BitwiseARModel(cfg).eval().to(dev)
     model.load_state_dict(sd, strict=True)
     model.set_precision(args.precision)
-    model.set_graphs(True, args.branches)
+    sk = [int(x) for x in args.splitk.split(",")]
+    model.set_graphs(True, args.branches, sk[0], sk[1])
     t_load = time.time() - t0
     log(f"rank {rank}: weights generated + loaded in {t_load:.1f} s")
 
@@ -191,6 +194,25 @@ def main():
         "parity": parity,
         "load_s": round(t_load, 1),
     }
+
+    # the same workload in the other GEMM mode (exact fp32 MFMA), outside the timed region: the f32 kernel is MFMA-bound and
+    # sits much closer to its (6x lower) roofline, the f16x3 kernel is faster in absolute terms
+    if world == 1 and args.precision == "f16x3" and not args.no_alt_mode:
+        model.set_precision("f32")
+        step(); torch.cuda.synchronize()
+        model.set_profiling(1)
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        dt32 = (time.perf_counter() - t1) / 2
+        p32 = model.get_profile()
+        model.set_profiling(0)
+        model.set_precision("f16x3")
+        tf32 = p32["dom_flop"] / (p32["dom_ms"] * 1e-3) / 1e12 if p32["dom_ms"] > 0 else 0.0
+        result["f32_mode"] = {"value": round(B * frames_per_clip / dt32, 1), "ms_per_step": round(dt32 * 1e3, 2),
+                              "roofline": {"bound": "mfma", "achieved": round(tf32, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": round(tf32 / PEAK_F32_MFMA_TFLOPS, 4), "kernel": MODES["f32"][2]}}
 
     if not args.no_cpu_baseline and world == 1:
         sys.path.insert(0, os.path.join(REPO, "oracle"))

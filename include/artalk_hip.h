@@ -129,7 +129,9 @@ int artalk_get_profile(artalk_model* m, double* out, int n);
  * both modes) at 5.3x the matrix-core rate; the logit / code heads stay on the fp32 path in both modes. */
 int artalk_set_precision(artalk_model* m, int mode);
 /* Replay the AR/VAE part from hipGraphs captured per active-batch size (default 1 = on).  The batch is cut into 1/2/4 clip
- * groups whose graphs run concurrently on separate streams (automatic; enable | (groups << 8) forces a count, for tuning). */
+ * groups whose graphs run concurrently on separate streams (automatic; enable | (groups << 8) forces a count, for tuning).
+ * Bits 16-23 / 24-31, when non-zero, override the split-K policy in units of 16 tiles (split when a GEMM has fewer output
+ * tiles than the first, aim for the second; defaults 192 / 384 measured best). */
 int artalk_set_graphs(artalk_model* m, int enable);
 
 /* ---- single-kernel entry points for the parity tests (device pointers, row-major f32) ---- */
