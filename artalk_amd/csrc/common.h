@@ -54,6 +54,125 @@ __device__ __forceinline__ void store_p8x4(float* row, int c, float x0, float x1
     *reinterpret_cast<f16x4_t*>(g + 16) = l;
 }
 
+// ---- GEMM epilogue for one 32x32 MFMA tile computed with the WEIGHT rows as the A operand and the activation rows as the B
+// operand, so that the accumulator is C^T: lane (r = lane & 31, h = lane >> 5) holds
+//     v[e] = C[row][col0 + (e & 3) + 8 * (e >> 2) + 4 * h],   row = (tile's first row) + r,
+// i.e. four runs of 4 consecutive columns.  Stores, residual and gate reads are therefore 16 bytes per lane (a quarter of the
+// vector-memory instructions of the column-per-lane layout: the store tail of a tile is instruction-issue bound, 7.6 us -> see
+// DESIGN.md), and a P8 result leaves as whole 32-byte groups after one half-wave exchange.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+struct EpiCtx {
+    const float* bias; float* C; const float* R; bool vec;
+};
+__device__ __forceinline__ EpiCtx make_epi(const GemmArgs& g, const float* bias, float* C, const float* R) {
+    EpiCtx x; x.bias = bias; x.C = C; x.R = R;
+    unsigned long long bits = (unsigned long long)(g.N | g.ldc) | ((unsigned long long)C >> 2);
+    if (bias) bits |= (unsigned long long)bias >> 2;
+    if (R) bits |= (unsigned long long)g.ldr | ((unsigned long long)R >> 2);
+    if (g.gate) bits |= (unsigned long long)g.ldg | ((unsigned long long)g.gate >> 2);
+    x.vec = (bits & 3) == 0;     // every row start and every run of 4 columns is 16-byte aligned
+    return x;
+}
+__device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx& x, int row, int col0, int h, f32x16& v) {   // v is clobbered
+    const bool rok = row < g.M;
+    const long crow = rok ? map_row(g.cmap, row) : 0;
+    const float* gp = (g.gate && rok) ? g.gate + (long)map_row(g.gmap, row) * g.ldg : nullptr;
+    const float* rp = (x.R && rok) ? x.R + crow * g.ldr : nullptr;
+    if (x.vec) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = col0 + 8 * q + 4 * h;
+            const bool ok = c < g.N;          // N % 4 == 0: the whole run is inside or outside
+            f32x4 b = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f}, rv = {0.f, 0.f, 0.f, 0.f};
+            if (x.bias && ok) b = *reinterpret_cast<const f32x4*>(x.bias + c);
+            if (gp && ok) gv = *reinterpret_cast<const f32x4*>(gp + c);
+            if (rp && ok) rv = *reinterpret_cast<const f32x4*>(rp + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = apply_act_rt(v[4 * q + e] + b[e], g.act);
+                if (g.gate) t *= gv[e];
+                v[4 * q + e] = t + rv[e];
+            }
+        }
+        if (g.c_p8) {   // N % 8 == 0.  Pairs of 8-column groups (k, k+1): lanes h=0 end up with all of group k, lanes h=1 with group k+1
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                unsigned int w[2][4];     // [group of the pair][hi.x, hi.y, lo.x, lo.y] of this lane's 4 columns
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    f16x4_t hh, ll;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = v[8 * qp + 4 * k + e];
+                        hh[e] = (_Float16)t;
+                        ll[e] = (_Float16)((t - (float)hh[e]) * 2048.0f);
+                    }
+                    const uint2 hu = __builtin_bit_cast(uint2, hh), lu = __builtin_bit_cast(uint2, ll);
+                    w[k][0] = hu.x; w[k][1] = hu.y; w[k][2] = lu.x; w[k][3] = lu.y;
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {   // v_permlane32_swap: upper half of w[0] <-> lower half of w[1]
+                    const auto sw = __builtin_amdgcn_permlane32_swap(w[0][d], w[1][d], false, false);
+                    w[0][d] = sw[0]; w[1][d] = sw[1];
+                }
+                const int gc = col0 + 16 * qp + 8 * h;
+                if (rok && gc < g.N) {
+                    unsigned char* o = reinterpret_cast<unsigned char*>(x.C + crow * g.ldc + gc);
+                    const u32x4_t hi = {w[0][0], w[0][1], w[1][0], w[1][1]}, lo = {w[0][2], w[0][3], w[1][2], w[1][3]};
+                    *reinterpret_cast<u32x4_t*>(o) = hi;
+                    *reinterpret_cast<u32x4_t*>(o + 16) = lo;
+                }
+            }
+        } else if (rok) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = col0 + 8 * q + 4 * h;
+                if (c < g.N) {
+                    const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(x.C + crow * g.ldc + c) = o;
+                }
+            }
+        }
+        return;
+    }
+    if (!rok) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {      // unaligned shapes (N = 106, odd leading dimensions): one column at a time
+        const int col = col0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (col < g.N) {
+            float t = apply_act_rt(v[e] + (x.bias ? x.bias[col] : 0.f), g.act);
+            if (gp) t *= gp[col];
+            if (rp) t += rp[col];
+            if (g.c_p8) {
+                _Float16* o = reinterpret_cast<_Float16*>(x.C + crow * g.ldc + (col & ~7));
+                const _Float16 hh = (_Float16)t;
+                o[col & 7] = hh;
+                o[8 + (col & 7)] = (_Float16)((t - (float)hh) * 2048.0f);
+            } else {
+                x.C[crow * g.ldc + col] = t;
+            }
+        }
+    }
+}
+// split-K partial slab of the same tile: raw sums, row-major [M][N]
+__device__ __forceinline__ void partial_tile32(const GemmArgs& g, float* P, int row, int col0, int h, const f32x16& v) {
+    if (row >= g.M) return;
+    float* p = P + (long)row * g.N;
+    if (((g.N | (int)((unsigned long long)P >> 2)) & 3) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = col0 + 8 * q + 4 * h;
+            if (c < g.N) { const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; *reinterpret_cast<f32x4*>(p + c) = o; }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int col = col0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (col < g.N) p[col] = v[e];
+        }
+    }
+}
+
 // full-wave (64 lanes) butterfly reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1205,6 +1205,7 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
     if (force_cfg >= 2) {   // LDS-DMA pipelined kernel (needs both operands in P8); 3 / 5 select the pipeline depth, 6 = 256x128 tiles, 2 = default
         if (!a_packed) return ARTALK_EINVAL;
         g.force_cfg = force_cfg == 2 ? -1 : force_cfg;
+        if (force_cfg == 16) { g.partial = (float*)bias; g.bias = nullptr; }   // timing build: `bias` carries the stamp buffer (8 x u64 per tile)
         launch_gemm_p8(g, (hipStream_t)stream);
     } else {
         launch_gemm_f16s(g, (hipStream_t)stream);

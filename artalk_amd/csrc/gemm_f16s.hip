@@ -180,9 +180,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                    // weight fragment as the A operand: the accumulator is C^T (common.h, epilogue_tile32)
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], accm[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], accx[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], accx[i][j], 0, 0, 0);
                 }
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
@@ -192,49 +193,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
     if (g.splitk > 1) {   // raw partial sums; the epilogue runs in splitk_reduce_kernel
         float* __restrict__ P = g.partial + (long)blockIdx.y * g.M * g.N;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / WN) + j * 32 + r;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (row < g.M && col < g.N) P[(long)row * g.N + col] = accm[i][j][e] + accx[i][j][e] * kLoInv;
-                }
-        }
+                for (int e = 0; e < 16; ++e) accm[i][j][e] += accx[i][j][e] * kLoInv;
+                partial_tile32(g, P, m0 + wm * (BM / WM) + i * 32 + r, n0 + wn * (BN / WN) + j * 32, h, accm[i][j]);
+            }
         return;
     }
-    const float* __restrict__ bias = g.bias ? g.bias + z * g.sBias : nullptr;
-    float* __restrict__ C = g.C + z * g.sC;
-    const float* R = g.R ? g.R + z * g.sR : nullptr;
+    const EpiCtx epi = make_epi(g, g.bias ? g.bias + z * g.sBias : nullptr, g.C + z * g.sC, g.R ? g.R + z * g.sR : nullptr);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (BN / WN) + j * 32 + r;
-        const bool cok = col < g.N;
-        const float bv = (bias && cok) ? bias[col] : 0.f;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < g.M && cok) {
-                    float v = (accm[i][j][e] + accx[i][j][e] * kLoInv) + bv;
-                    v = apply_act_rt(v, g.act);
-                    if (g.gate) v *= g.gate[(long)map_row(g.gmap, row) * g.ldg + col];
-                    const long crow = map_row(g.cmap, row);
-                    if (R) v += R[crow * g.ldr + col];
-                    if (g.c_p8) {   // hand the result to the next split GEMM already in P8
-                        _Float16* o = reinterpret_cast<_Float16*>(C + crow * g.ldc + (col & ~7));
-                        const _Float16 hh = (_Float16)v;
-                        o[col & 7] = hh;
-                        o[8 + (col & 7)] = (_Float16)((v - (float)hh) * kLoScale);
-                    } else {
-                        C[crow * g.ldc + col] = v;
-                    }
-                }
-            }
+            for (int e = 0; e < 16; ++e) accm[i][j][e] += accx[i][j][e] * kLoInv;
+            epilogue_tile32(g, epi, m0 + wm * (BM / WM) + i * 32 + r, n0 + wn * (BN / WN) + j * 32, h, accm[i][j]);
         }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -248,6 +224,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
 //   of the DMA and again on the fragment read (same involution), which makes the ds_read_b128 fragment reads conflict-free.
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Fragment reads and their waits are hand-placed: while an LDS-DMA is pending hipcc treats it as a FLAT access to both memories
+// and turns every wait it inserts for a ds_read result into lgkmcnt(0), which drains the reads issued for the NEXT half step in
+// front of MFMAs that do not need them.  The sched_barrier keeps register-only MFMAs from being hoisted above the wait.
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int OFF>
+__device__ __forceinline__ f16x8 lds_read128(unsigned addr) {
+    f16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
 template <int UNIT>
 __device__ __forceinline__ void wait_vmcnt_units(int units) {   // at most `units` groups of UNIT DMA instructions stay in flight
     if (units >= 3) wait_vmcnt<3 * UNIT>();
@@ -258,7 +248,9 @@ __device__ __forceinline__ void wait_vmcnt_units(int units) {   // at most `unit
 
 // BM = 128: waves 2 x 4, wave tile 64 x 32, 4 stages of 32 KiB.  BM = 256: waves 4 x 2, wave tile 64 x 64, 3 stages of 48 KiB
 // (3/4 of the operand bytes per flop).
-template <int BM, int STAGES>
+// ABL == 6 (tools/gemm_p8_stamps.py): the same kernel + wall-clock stamps (100 MHz) per workgroup in g.partial as 8 x u64:
+// entry, first stage landed, main loop done, epilogue done, HW_ID, XCC_ID.
+template <int BM, int STAGES, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
     constexpr int BN = 128, BK = 32;
     constexpr int WN_WAVES = (BM == 128) ? 4 : 2;          // waves along N
@@ -270,6 +262,15 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
 
     const int tid = threadIdx.x;
+    unsigned long long* stamps = nullptr;
+    if constexpr (ABL == 6) {
+        stamps = reinterpret_cast<unsigned long long*>(g.partial) + (long)blockIdx.x * 8;
+        if (tid == 0) {
+            stamps[0] = wall_clock64();
+            stamps[4] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID, all 32 bits
+            stamps[5] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+        }
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
     int tm, tn;
@@ -303,33 +304,39 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
         const int gn = min(n0 + rw, g.N - 1);
         wsrc[q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw) * 4 + ((pchunk ^ ((rw >> 1) & 7)) << 4);
     }
-    auto issue = [&](int kt, int buf) {
+    // piece q of this wave for K tile kt into ring buffer buf: q < APIECES -> A rows, else W rows
+    auto issue_piece = [&](int q, int kt, int buf) {
         unsigned char* base = smem_p8 + buf * STAGE_BYTES;
         const long koff = (long)kt * (BK * 4);
-#pragma unroll
-        for (int q = 0; q < APIECES; ++q)
+        if (q < APIECES)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[q] + koff),
                                              (__attribute__((address_space(3))) void*)(base + (wave * APIECES + q) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q - APIECES] + koff),
+                                             (__attribute__((address_space(3))) void*)(base + BM * 128 + (wave * WPIECES + q - APIECES) * 1024), 16, 0, 0);
+    };
+    auto issue = [&](int kt, int buf) {
 #pragma unroll
-        for (int q = 0; q < WPIECES; ++q)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + koff),
-                                             (__attribute__((address_space(3))) void*)(base + BM * 128 + (wave * WPIECES + q) * 1024), 16, 0, 0);
+        for (int q = 0; q < NDMA; ++q) issue_piece(q, kt, buf);
     };
 
     const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
     const int r = lane & 31, h = lane >> 5;
-    int a_row_off[2], a_key[2], w_row_off[TN], w_key[TN];
+    // LDS byte addresses of this lane's fragments inside a stage, [kb][hi/lo]; the second m tile (and n tile) is 32 rows = 4096 B
+    // further on with the same swizzle key, which goes into the instruction's immediate offset
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_p8;
+    unsigned a_off[2][2], w_off[2][2];
+    {
+        const int arow = wm * 64 + r, wrow = wn * (32 * TN) + r;
+        const int akey = (arow >> 1) & 7, wkey = (wrow >> 1) & 7;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + i * 32 + r;
-        a_row_off[i] = row * 128;
-        a_key[i] = (row >> 1) & 7;
-    }
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int row = wn * (32 * TN) + j * 32 + r;
-        w_row_off[j] = BM * 128 + row * 128;
-        w_key[j] = (row >> 1) & 7;
+            for (int lo = 0; lo < 2; ++lo) {
+                const int c = (kb * 2 + h) * 2 + lo;     // logical 16-byte chunk: hi fragment, lo = the next one
+                a_off[kb][lo] = lds0 + arow * 128 + ((c ^ akey) << 4);
+                w_off[kb][lo] = lds0 + BM * 128 + wrow * 128 + ((c ^ wkey) << 4);
+            }
     }
 
     f32x16 accm[2][TN], accx[2][TN];
@@ -346,81 +353,103 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
         if (st < nk) issue(st, st);
 
     // Fragment registers are one half-step ahead of the MFMAs, so LDS-read latency and the stage hand-over (vmcnt wait +
-    // barrier) sit under matrix work instead of in front of it:
-    //   iteration kt:  read kb=1 frags of stage kt | MFMA kb=0 | wait stage kt+1, barrier, DMA stage kt+S-1 |
-    //                  read kb=0 frags of stage kt+1 | MFMA kb=1
-    auto read_frags = [&](const unsigned char* base, int kb, f16x8 (&ah)[2], f16x8 (&al)[2], f16x8 (&bh)[TN], f16x8 (&bl)[TN]) {
-        const int c = (kb * 2 + h) * 2;               // logical chunk of the hi fragment; lo = c + 1
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ah[i] = *reinterpret_cast<const f16x8*>(base + a_row_off[i] + ((c ^ a_key[i]) << 4));
-            al[i] = *reinterpret_cast<const f16x8*>(base + a_row_off[i] + (((c + 1) ^ a_key[i]) << 4));
+    // barrier) sit under matrix work instead of in front of it.  Steady-state iteration kt (branch-free, so that hipcc counts
+    // its lgkmcnt waits exactly instead of draining at a join):
+    //   read kb=1 frags of stage kt | 6 MFMA kb=0 | vmcnt: stage kt+1 landed | barrier |
+    //   read kb=0 frags of stage kt+1 | 6 MFMA kb=1 with the DMA pieces of stage kt+S-1 issued one per MFMA gap
+    // The DMA reuses the buffer of stage kt-1, whose fragment reads were all consumed by MFMAs issued before this barrier, so no
+    // lgkmcnt drain is needed in front of the barrier and the kb=1 reads of stage kt stay in flight across it.
+    constexpr int NRD = 4 + 2 * TN;    // ds_read_b128 per half step
+    auto read_frags = [&](int buf, int kb, f16x8 (&ah)[2], f16x8 (&al)[2], f16x8 (&bh)[TN], f16x8 (&bl)[TN]) {
+        const unsigned sb = buf * STAGE_BYTES;
+        const unsigned ahp = a_off[kb][0] + sb, alp = a_off[kb][1] + sb, whp = w_off[kb][0] + sb, wlp = w_off[kb][1] + sb;
+        bh[0] = lds_read128<0>(whp);
+        ah[0] = lds_read128<0>(ahp);
+        bl[0] = lds_read128<0>(wlp);
+        al[0] = lds_read128<0>(alp);
+        ah[1] = lds_read128<4096>(ahp);
+        al[1] = lds_read128<4096>(alp);
+        if constexpr (TN == 2) {
+            bh[TN - 1] = lds_read128<4096>(whp);
+            bl[TN - 1] = lds_read128<4096>(wlp);
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            bh[j] = *reinterpret_cast<const f16x8*>(base + w_row_off[j] + ((c ^ w_key[j]) << 4));
-            bl[j] = *reinterpret_cast<const f16x8*>(base + w_row_off[j] + (((c + 1) ^ w_key[j]) << 4));
-        }
+    };
+    constexpr int NMF = 2 * TN * 3;    // MFMAs per half step
+    auto mfma_slot = [&](int sidx, const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
+        const int i = sidx / (3 * TN), j = (sidx / 3) % TN, t = sidx % 3;     // weight fragment = A operand: C^T, see epilogue_tile32
+        if (t == 0) accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], accm[i][j], 0, 0, 0);
+        else if (t == 1) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], accx[i][j], 0, 0, 0);
+        else accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], accx[i][j], 0, 0, 0);
     };
     auto mfmas = [&](const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
-                accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
-                accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
-            }
+        for (int sidx = 0; sidx < NMF; ++sidx) mfma_slot(sidx, ah, al, bh, bl);
     };
 
     f16x8 ah0[2], al0[2], bh0[TN], bl0[TN], ah1[2], al1[2], bh1[TN], bl1[TN];
     wait_vmcnt_units<NDMA>(min(STAGES - 2, nk - 1));   // stage 0 landed (the prologue left up to STAGES-2 younger stages in flight)
     __builtin_amdgcn_s_barrier();
-    read_frags(smem_p8, 0, ah0, al0, bh0, bl0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned char* base = smem_p8 + (kt % STAGES) * STAGE_BYTES;
-        read_frags(base, 1, ah1, al1, bh1, bl1);
+    if constexpr (ABL == 6) { if (tid == 0) stamps[1] = wall_clock64(); }
+    read_frags(0, 0, ah0, al0, bh0, bl0);
+    int kt = 0, buf = 0;                               // buf = kt % STAGES
+    for (; kt + STAGES - 1 < nk; ++kt) {               // steady state: stage kt+S-1 still to be fetched
+        const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
+        const int fbuf = (buf == 0) ? STAGES - 1 : buf - 1;     // (kt + S - 1) % S
+        read_frags(buf, 1, ah1, al1, bh1, bl1);
+        wait_lgkmcnt<NRD>();                           // the kb=0 fragments (issued half a step ago) are in; the kb=1 reads fly on
         mfmas(ah0, al0, bh0, bl0);
-        if (kt + 1 < nk) {
-            wait_vmcnt_units<NDMA>(min(STAGES - 3, nk - 2 - kt));    // stage kt+1 landed for this wave
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // my reads of stage kt are back before anyone may overwrite it
-            __builtin_amdgcn_s_barrier();                             // stage kt+1 visible to all; all waves are done with stage kt-1
-            if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);   // reuses the buffer of stage kt-1
-            read_frags(smem_p8 + ((kt + 1) % STAGES) * STAGE_BYTES, 0, ah0, al0, bh0, bl0);
-        }
-        mfmas(ah1, al1, bh1, bl1);
-    }
-
-    const float* __restrict__ bias = g.bias;
-    float* __restrict__ C = g.C;
-    const float* R = g.R;
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt<(STAGES - 3) * NDMA>();             // stage kt+1 landed for this wave (stages kt+2 .. kt+S-2 may still fly)
+        __builtin_amdgcn_s_barrier();                  // ... and for every wave; every wave is done with stage kt-1
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(nbuf, 0, ah0, al0, bh0, bl0);
+        wait_lgkmcnt<NRD>();                           // kb=1 fragments of stage kt
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (32 * TN) + j * 32 + r;
-        const bool cok = col < g.N;
-        const float bv = (bias && cok) ? bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < g.M && cok) {
-                    float v = (accm[i][j][e] + accx[i][j][e] * kLoInv) + bv;
-                    v = apply_act_rt(v, g.act);
-                    if (g.gate) v *= g.gate[(long)map_row(g.gmap, row) * g.ldg + col];
-                    const long crow = map_row(g.cmap, row);
-                    if (R) v += R[crow * g.ldr + col];
-                    if (g.c_p8) {   // hand the result to the next split GEMM already in P8 (element col -> hi/lo planes of its group)
-                        _Float16* o = reinterpret_cast<_Float16*>(C + crow * g.ldc + (col & ~7));
-                        const _Float16 hh = (_Float16)v;
-                        o[col & 7] = hh;
-                        o[8 + (col & 7)] = (_Float16)((v - (float)hh) * kLoScale);
-                    } else {
-                        C[crow * g.ldc + col] = v;
-                    }
-                }
+        for (int sidx = 0; sidx < NMF; ++sidx) {
+            mfma_slot(sidx, ah1, al1, bh1, bl1);
+            if (sidx < NDMA) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece(sidx, kt + STAGES - 1, fbuf);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nbuf;
+    }
+    for (; kt < nk; ++kt) {                            // drain: the last S-1 stages are in flight or landed
+        const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
+        read_frags(buf, 1, ah1, al1, bh1, bl1);
+        wait_lgkmcnt<NRD>();
+        mfmas(ah0, al0, bh0, bl0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            wait_vmcnt_units<NDMA>(min(STAGES - 3, nk - 2 - kt));
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(nbuf, 0, ah0, al0, bh0, bl0);
+            wait_lgkmcnt<NRD>();
+        } else {
+            wait_lgkmcnt<0>();
+        }
+        mfmas(ah1, al1, bh1, bl1);
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nbuf;
+    }
+    if constexpr (ABL == 6) { if (tid == 0) stamps[2] = wall_clock64(); }
+
+    const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accm[i][j][e] += accx[i][j][e] * kLoInv;
+            epilogue_tile32(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * (32 * TN) + j * 32, h, accm[i][j]);
+        }
+    if constexpr (ABL == 6) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) stamps[3] = wall_clock64();
     }
 }
 
@@ -431,6 +460,7 @@ void launch_gemm_p8(const GemmArgs& g, hipStream_t s) {
         case 3: hipLaunchKernelGGL((gemm_p8_kernel<128, 3>), dim3(t128), dim3(512), 3 * 256 * 128, s, g); break;
         case 5: hipLaunchKernelGGL((gemm_p8_kernel<128, 5>), dim3(t128), dim3(512), 5 * 256 * 128, s, g); break;
         case 6: hipLaunchKernelGGL((gemm_p8_kernel<256, 3>), dim3(t256), dim3(512), 3 * 384 * 128, s, g); break;
+        case 16: hipLaunchKernelGGL((gemm_p8_kernel<128, 4, 6>), dim3(t128), dim3(512), 4 * 256 * 128, s, g); break;
         default: hipLaunchKernelGGL((gemm_p8_kernel<128, 4>), dim3(t128), dim3(512), 4 * 256 * 128, s, g); break;
     }
 }

@@ -134,51 +134,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q][e], b[j][q][e], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][q][e], a[i][q][e], acc[i][j], 0, 0, 0);   // C^T: epilogue_tile32
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+    // ---- epilogue: the weight fragment is the A operand, so lane (r, h) holds 4 x 4 consecutive columns of row r (common.h) ----
     if (g.splitk > 1) {   // raw partial sums; bias/act/gate/residual are applied by splitk_reduce_kernel
         float* __restrict__ P = g.partial + (long)blockIdx.y * g.M * g.N;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / WN) + j * 32 + r;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (row < g.M && col < g.N) P[(long)row * g.N + col] = acc[i][j][e];
-                }
-        }
+            for (int j = 0; j < TN; ++j) partial_tile32(g, P, m0 + wm * (BM / WM) + i * 32 + r, n0 + wn * (BN / WN) + j * 32, h, acc[i][j]);
         return;
     }
-    const float* __restrict__ bias = g.bias ? g.bias + z * g.sBias : nullptr;
-    float* __restrict__ C = g.C + z * g.sC;
-    const float* R = g.R ? g.R + z * g.sR : nullptr;
+    const EpiCtx epi = make_epi(g, g.bias ? g.bias + z * g.sBias : nullptr, g.C + z * g.sC, g.R ? g.R + z * g.sR : nullptr);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (BN / WN) + j * 32 + r;
-        const bool cok = col < g.N;
-        const float bv = (bias && cok) ? bias[col] : 0.f;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < g.M && cok) {
-                    float v = acc[i][j][e] + bv;
-                    v = apply_act_rt(v, g.act);
-                    if (g.gate) v *= g.gate[(long)map_row(g.gmap, row) * g.ldg + col];
-                    const long crow = map_row(g.cmap, row);
-                    if (R) v += R[crow * g.ldr + col];
-                    C[crow * g.ldc + col] = v;
-                }
-            }
-        }
-    }
+        for (int j = 0; j < TN; ++j) epilogue_tile32(g, epi, m0 + wm * (BM / WM) + i * 32 + r, n0 + wn * (BN / WN) + j * 32, h, acc[i][j]);
 }
 
 template <int BM, int BN, int WM, int WN, int BK = 32>
