@@ -128,7 +128,7 @@ def lib() -> C.CDLL:
     L.artalk_set_precision.restype = i32
     L.artalk_op_gemm_f16s.argtypes = [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.artalk_op_gemm_f16s.restype = i32
-    L.artalk_op_pack_split.argtypes = [vp, vp, i64, vp]
+    L.artalk_op_pack_split.argtypes = [vp, vp, i64, i32, vp]
     L.artalk_op_pack_split.restype = i32
     L.artalk_op_gemm_f16s_packed.argtypes = [vp, i32, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.artalk_op_gemm_f16s_packed.restype = i32

@@ -38,17 +38,24 @@ __device__ __forceinline__ float apply_act_rt(float x, int act) {
     }
 }
 
-// ---- "P8" split format (gemm_f16s.hip): every 8 consecutive elements of a row become 32 bytes [8 x f16 hi][8 x f16 lo],
-// x = hi + lo/2048.  Same pitch as fp32.  store_p8x4 writes elements c..c+3 (c % 4 == 0) of a row whose storage starts at `row`.
+// ---- "P8" split format (gemm_f16s.hip): an operand x is first scaled by a power of two S (activations kActScale, weights
+// kWScale), then every 8 consecutive elements of a row become 32 bytes [8 x f16 hi][8 x f16 lo] with hi = f16(S x) and
+// lo = f16(S x - hi) (UNSCALED residual; gfx950's f16 MFMA honours subnormal inputs - tools/mfma_subnormal_probe.py - so a
+// residual below 2^-14 still carries 2^-25 absolute precision).  Same pitch as fp32.  Because both halves are in one scale,
+// hi*hi + hi*lo + lo*hi accumulate in ONE fp32 accumulator; the GEMM epilogue multiplies by kOutScale = 1/(SA*SW) (exact).
+// Range: |x| < 65504/16 = 4094 for activations, < 255 for weights (overflow -> inf -> status word -> exact-f32 re-run).
+constexpr float kActScale = 16.0f, kWScale = 256.0f, kOutScale = 1.0f / (16.0f * 256.0f);
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_f16(float xs, _Float16& hi, _Float16& lo) {   // xs already scaled
+    hi = (_Float16)xs;
+    lo = (_Float16)(xs - (float)hi);
+}
+// store_p8x4 writes activation elements c..c+3 (c % 4 == 0) of a row whose storage starts at `row`.
 __device__ __forceinline__ void store_p8x4(float* row, int c, float x0, float x1, float x2, float x3) {
     const float x[4] = {x0, x1, x2, x3};
     f16x4_t h, l;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        h[e] = (_Float16)x[e];
-        l[e] = (_Float16)((x[e] - (float)h[e]) * 2048.0f);
-    }
+    for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f16(x[e] * kActScale, a, b); h[e] = a; l[e] = b; }
     unsigned char* g = reinterpret_cast<unsigned char*>(row) + (c >> 3) * 32 + (c & 4) * 2;
     *reinterpret_cast<f16x4_t*>(g) = h;
     *reinterpret_cast<f16x4_t*>(g + 16) = l;
@@ -103,9 +110,9 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
                     f16x4_t hh, ll;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float t = v[8 * qp + 4 * k + e];
-                        hh[e] = (_Float16)t;
-                        ll[e] = (_Float16)((t - (float)hh[e]) * 2048.0f);
+                        _Float16 a, b;
+                        split_f16(v[8 * qp + 4 * k + e] * kActScale, a, b);
+                        hh[e] = a; ll[e] = b;
                     }
                     const uint2 hu = __builtin_bit_cast(uint2, hh), lu = __builtin_bit_cast(uint2, ll);
                     w[k][0] = hu.x; w[k][1] = hu.y; w[k][2] = lu.x; w[k][3] = lu.y;
@@ -145,15 +152,79 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
             if (rp) t += rp[col];
             if (g.c_p8) {
                 _Float16* o = reinterpret_cast<_Float16*>(x.C + crow * g.ldc + (col & ~7));
-                const _Float16 hh = (_Float16)t;
+                _Float16 hh, ll;
+                split_f16(t * kActScale, hh, ll);
                 o[col & 7] = hh;
-                o[8 + (col & 7)] = (_Float16)((t - (float)hh) * 2048.0f);
+                o[8 + (col & 7)] = ll;
             } else {
                 x.C[crow * g.ldc + col] = t;
             }
         }
     }
 }
+// ---- Coalesced epilogue through wave-private LDS (the LDS-DMA kernels, whose LDS is free after the main loop).  The store tail
+// of a tile is bound by vector-memory INSTRUCTIONS whose lanes scatter over many rows (a C^T accumulator tile stores 32 rows x 32 B
+// per instruction: 256 KiB of a 256x256 tile took 33 us); transposed through LDS every instruction covers whole row segments.
+// epilogue_row4: one lane owns 4 consecutive columns (col % 4 == 0) of one row; needs x.vec (16-byte aligned rows, N % 4 == 0).
+// For a P8 result adjacent lanes (col, col+4 of one 8-group) trade halves so that each writes one 16-byte hi or lo chunk; all 64
+// lanes must be active when it is called.
+__device__ __forceinline__ void epilogue_row4(const GemmArgs& g, const EpiCtx& x, int row, int col, f32x4 v) {
+    const bool ok = row < g.M && col < g.N;
+    const long crow = ok ? map_row(g.cmap, row) : 0;
+    f32x4 b = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f}, rv = {0.f, 0.f, 0.f, 0.f};
+    if (x.bias && ok) b = *reinterpret_cast<const f32x4*>(x.bias + col);
+    if (g.gate && ok) gv = *reinterpret_cast<const f32x4*>(g.gate + (long)map_row(g.gmap, row) * g.ldg + col);
+    if (x.R && ok) rv = *reinterpret_cast<const f32x4*>(x.R + crow * g.ldr + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = apply_act_rt(v[e] + b[e], g.act);
+        if (g.gate) t *= gv[e];
+        v[e] = t + rv[e];
+    }
+    if (g.c_p8) {
+        f16x4_t hh, ll;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { _Float16 a, c; split_f16(v[e] * kActScale, a, c); hh[e] = a; ll[e] = c; }
+        const uint2 hu = __builtin_bit_cast(uint2, hh), lu = __builtin_bit_cast(uint2, ll);
+        const bool odd = (col & 4) != 0;                      // second half of the 8-group: keeps lo, gives hi away
+        const unsigned sx = odd ? hu.x : lu.x, sy = odd ? hu.y : lu.y;
+        const unsigned rx = __builtin_amdgcn_mov_dpp(sx, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: the neighbour lane's value
+        const unsigned ry = __builtin_amdgcn_mov_dpp(sy, 0xB1, 0xF, 0xF, true);
+        if (ok) {
+            unsigned char* o = reinterpret_cast<unsigned char*>(x.C + crow * g.ldc + (col & ~7)) + (odd ? 16 : 0);
+            const u32x4_t w = odd ? u32x4_t{rx, ry, lu.x, lu.y} : u32x4_t{hu.x, hu.y, rx, ry};
+            *reinterpret_cast<u32x4_t*>(o) = w;
+        }
+    } else if (ok) {
+        *reinterpret_cast<f32x4*>(x.C + crow * g.ldc + col) = v;
+    }
+}
+// NI x NJ accumulator tiles (C^T layout, already scaled) of one wave = rows row0.. (32 NI) x cols col0.. (32 NJ) -> wave-private LDS
+// (>= 32 NI * (32 NJ + 4) floats, nobody else touches it) -> row-major epilogue, 64/(8 NJ) rows per instruction.
+template <int NI, int NJ>
+__device__ __forceinline__ void epilogue_wave_lds(const GemmArgs& g, const EpiCtx& x, float* lds, int row0, int col0, int lane,
+                                                  f32x16 (&acc)[NI][NJ]) {
+    constexpr int COLS = 32 * NJ, PITCH = COLS + 4, LPR = COLS / 4, RPI = 64 / LPR;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 t = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(lds + (i * 32 + r) * PITCH + j * 32 + 8 * q + 4 * h) = t;
+            }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int rr = lane / LPR, cc = (lane % LPR) * 4;
+#pragma unroll
+    for (int it = 0; it < 32 * NI / RPI; ++it) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + (it * RPI + rr) * PITCH + cc);
+        epilogue_row4(g, x, row0 + it * RPI + rr, col0 + cc, v);
+    }
+}
+
 // split-K partial slab of the same tile: raw sums, row-major [M][N]
 __device__ __forceinline__ void partial_tile32(const GemmArgs& g, float* P, int row, int col0, int h, const f32x16& v) {
     if (row >= g.M) return;

@@ -366,7 +366,7 @@ void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
         }
     }
     const bool dominant = !m->in_body && g.M > 0 &&
-                          (split ? (g.a_packed ? gemm_p8_eligible(g) : gemm_f16s_config(g) == 0) : gemm_config(g) == 4);
+                          (split ? (g.a_packed ? (gemm_p8_eligible(g) && gemm_p8_variant(g) == 0) : gemm_f16s_config(g) == 0) : gemm_config(g) == 4);
     size_t i0 = 0, i1 = 0;
     if (m->profiling && dominant) next_event(m, s, &i0);
     if (g.a_packed && !split) { m->err = "internal: P8 activation handed to an fp32 GEMM"; m->sticky_error = true; return; }
@@ -924,7 +924,7 @@ int artalk_finalize_weights(artalk_model* m) {
         if (r.n < 1024 || r.packed) continue;
         r.packed = dalloc<unsigned int>(m, r.n);
         if (!r.packed) return fail(m, ARTALK_EHIP, "hipMalloc failed for packed weights");
-        launch_pack_split(r.base, r.packed, r.n, nullptr);
+        launch_pack_split(r.base, r.packed, r.n, true, nullptr);
     }
     HIPCHK(m, hipDeviceSynchronize());
     m->finalized = true;
@@ -1173,14 +1173,14 @@ int artalk_op_gemm_f16s(const float* A, int64_t lda, const float* W, const float
     hipStream_t s = (hipStream_t)stream;
     unsigned int* wp = nullptr;
     if (hipMalloc(&wp, (size_t)N * K * 4) != hipSuccess) return ARTALK_EHIP;
-    launch_pack_split(W, wp, (long)N * K, s);
+    launch_pack_split(W, wp, (long)N * K, true, s);
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.Wp = wp; g.ldw = K; g.bias = bias; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
     g.force_cfg = force_cfg & 0xff;
     unsigned int* ap = nullptr;
     if (force_cfg >= 0 && (force_cfg & 0x100)) {   // tuning: pre-packed A (what a fused producer would hand over)
         if (hipMalloc(&ap, (size_t)M * lda * 4) != hipSuccess) return ARTALK_EHIP;
-        launch_pack_split(A, ap, (long)M * lda, s);
+        launch_pack_split(A, ap, (long)M * lda, false, s);
         g.A = reinterpret_cast<const float*>(ap); g.a_packed = 1;
     }
     launch_gemm_f16s(g, s);
@@ -1191,9 +1191,9 @@ int artalk_op_gemm_f16s(const float* A, int64_t lda, const float* W, const float
 }
 
 // building blocks for tuning the split GEMM without allocation noise: pack once, then launch on packed operands
-int artalk_op_pack_split(const float* in, void* out_u32, int64_t n, void* stream) {
+int artalk_op_pack_split(const float* in, void* out_u32, int64_t n, int is_weight, void* stream) {
     if (!in || !out_u32 || n <= 0) return ARTALK_EINVAL;
-    launch_pack_split(in, (unsigned int*)out_u32, n, (hipStream_t)stream);
+    launch_pack_split(in, (unsigned int*)out_u32, n, is_weight != 0, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }
 int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const void* Wp, const float* bias, float* C, int M, int N,
@@ -1204,8 +1204,8 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
     g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act; g.force_cfg = force_cfg;
     if (force_cfg >= 2) {   // LDS-DMA pipelined kernel (needs both operands in P8); 3 / 5 select the pipeline depth, 6 = 256x128 tiles, 2 = default
         if (!a_packed) return ARTALK_EINVAL;
-        g.force_cfg = force_cfg == 2 ? -1 : force_cfg;
-        if (force_cfg == 16) { g.partial = (float*)bias; g.bias = nullptr; }   // timing build: `bias` carries the stamp buffer (8 x u64 per tile)
+        g.force_cfg = force_cfg == 9 ? -1 : force_cfg;   // 9: the engine's own choice between the production kernels (7 / 8)
+        if (force_cfg >= 16 && force_cfg <= 18) { g.partial = (float*)bias; g.bias = nullptr; }   // timing build: `bias` carries the stamp buffer (8 x u64 per tile)
         launch_gemm_p8(g, (hipStream_t)stream);
     } else {
         launch_gemm_f16s(g, (hipStream_t)stream);

@@ -1,20 +1,24 @@
 // fp32-accurate GEMM on the fp16 matrix cores by operand splitting ("f16x3"): C = epilogue(A[M,K] * W[N,K]^T).
 //
-// Every fp32 operand x is represented as hi + lo/2048 with hi = f16(x) and lo = f16((x - hi) * 2048): 22 significand
-// bits, the residual is scaled so it stays in fp16's normal range.  A product a*b then needs three exact fp16 products
-//   a_hi*b_hi                (accumulator "main")
-//   a_hi*b_lo + a_lo*b_hi    (accumulator "cross", scaled by 2^-11 once in the epilogue)
-// accumulated in fp32 by v_mfma_f32_32x32x16_f16; the dropped a_lo*b_lo term is 2^-22 relative.  Measured on random
-// data (K = 1024): max error 8e-8 of the output scale, below the 5e-7 accumulation-order noise of any fp32 GEMM, and
-// every reference golden stays decision-exact (tests/test_e2e_gpu.py runs both precision modes).  Three fp16 MFMAs
-// cover 16 k in 96 cycles where v_mfma_f32_32x32x2_f32 needs 512: the MFMA time drops 5.3x and the kernel becomes
-// staging-bound.  fp16 range: |x| must stay below 65504 (all GEMM inputs of the path are LayerNorm/GELU/attention
-// outputs or weights); operands are never denormal-flushed (residuals are rescaled).
+// Every fp32 operand x is scaled by a power of two (activations 16, weights 256: common.h) and represented as hi + lo with
+// hi = f16(Sx) and lo = f16(Sx - hi): 22 significand bits (the residual may be an fp16 subnormal, which the gfx950 MFMA
+// honours).  A product a*b then needs three exact fp16 products  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, all accumulated into ONE
+// fp32 accumulator by v_mfma_f32_32x32x16_f16 (both halves share a scale); the dropped a_lo*b_lo term is 2^-22 relative and
+// the epilogue removes the operand scales with one exact multiply.  Measured on random data (K = 1024): error a few 1e-7 of
+// the output scale, at the accumulation-order noise of any fp32 GEMM, and every reference golden stays decision-exact
+// (tests/test_e2e_gpu.py runs both precision modes).  Three fp16 MFMAs cover 16 k in 96 cycles where v_mfma_f32_32x32x2_f32
+// needs 512: the MFMA time drops 5.3x and the kernels become staging-bound, which is why the accumulator count matters: one
+// accumulator per output tile (not main + cross) lets a wave own twice the output and halves the operand bytes per flop.
+// fp16 range: |x| < 4094 for activations, < 255 for weights (all GEMM inputs of the path are LayerNorm/GELU/attention outputs
+// or weights); an overflow becomes inf and is caught by the model's status word (exact-f32 re-run).
 //
-// Memory layout is unchanged: activations stay fp32 in HBM and are split while they are staged into LDS; weights are
-// pre-split once at load into the "P8" format (every 8 elements -> 16 bytes of hi halves + 16 bytes of lo halves), so
-// a packed matrix has the same size, pitch and 16-byte loads as the fp32 one and a 16-byte chunk is an MFMA fragment.  LDS rows hold the hi plane (BK halves) followed by the
-// lo plane, padded to 144 bytes (conflict-free ds_read_b128 for the 32x32x16 operand map: lane (r,h) holds k = 8h..8h+7).
+// Memory layout is unchanged: activations stay fp32 in HBM and are split while they are staged into LDS (or arrive already
+// split from their producer kernel); weights are pre-split once at load into the "P8" format (every 8 elements -> 16 bytes of
+// hi halves + 16 bytes of lo halves), so a packed matrix has the same size, pitch and 16-byte loads as the fp32 one and a
+// 16-byte chunk is an MFMA fragment.  LDS rows (register-staged kernel) hold the hi plane (BK halves) followed by the lo
+// plane, padded to 144 bytes (conflict-free ds_read_b128 for the 32x32x16 operand map: lane (r,h) holds k = 8h..8h+7).
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace artalk {
@@ -24,15 +28,10 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
-
-__device__ __forceinline__ void split_f32x4(const f32x4 x, u32x2& hi, u32x2& lo) {
+__device__ __forceinline__ void split_f32x4(const f32x4 x, const float scale, u32x2& hi, u32x2& lo) {
     f16x4 h, l;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        h[e] = (_Float16)x[e];
-        l[e] = (_Float16)((x[e] - (float)h[e]) * kLoScale);
-    }
+    for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f16(x[e] * scale, a, b); h[e] = a; l[e] = b; }
     hi = __builtin_bit_cast(u32x2, h);
     lo = __builtin_bit_cast(u32x2, l);
 }
@@ -44,21 +43,21 @@ __device__ __forceinline__ int p8_lds_offset(int c) { return (c & 1) * 64 + (c >
 // fp32 -> "P8" split format, 8 elements per thread: each group of 8 consecutive elements becomes 32 bytes
 // [8 x f16 hi][8 x f16 lo] (same size as the 8 floats it replaces, so a P8 matrix keeps the fp32 matrix's pitch and
 // indexing).  A 16-byte chunk of a P8 row is therefore directly an MFMA operand fragment (k = 8h .. 8h+7).
-__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, unsigned int* __restrict__ out, long n) {
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, unsigned int* __restrict__ out, long n, float scale) {
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long)gridDim.x * 2048) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(w + i), b = *reinterpret_cast<const f32x4*>(w + i + 4);
         u32x2 h0, l0, h1, l1;
-        split_f32x4(a, h0, l0);
-        split_f32x4(b, h1, l1);
+        split_f32x4(a, scale, h0, l0);
+        split_f32x4(b, scale, h1, l1);
         u32x4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
         *reinterpret_cast<u32x4*>(out + i) = hi;
         *reinterpret_cast<u32x4*>(out + i + 4) = lo;
     }
 }
-void launch_pack_split(const float* w, unsigned int* out, long n, hipStream_t s) {
+void launch_pack_split(const float* w, unsigned int* out, long n, bool is_weight, hipStream_t s) {
     if (n <= 0) return;
     const long blocks = (n / 8 + 255) / 256;   // n % 8 == 0 (every packed tensor has an inner dimension that is a multiple of 32)
-    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, w, out, n);
+    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, w, out, n, is_weight ? kWScale : kActScale);
 }
 
 // AMODE 1: grouped positional-conv window gather (see gemm_f32.hip), grid.z = group, fp32 A only.
@@ -130,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
                 *reinterpret_cast<u32x4*>(p + p8_lds_offset(tid & 7)) = ra[i];
             } else {
                 u32x2 hi, lo;
-                split_f32x4(__builtin_bit_cast(f32x4, ra[i]), hi, lo);
+                split_f32x4(__builtin_bit_cast(f32x4, ra[i]), kActScale, hi, lo);
                 *reinterpret_cast<u32x2*>(p + lc4 * 2) = hi;
                 *reinterpret_cast<u32x2*>(p + lc4 * 2 + 64) = lo;
             }
@@ -145,13 +144,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
 
-    f32x16 accm[TM][TN], accx[TM][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { accm[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk_all = g.K / BK;   // split-K: this workgroup owns K steps [kt0, nk)
     const int kt0 = (int)((long)nk_all * blockIdx.y / g.splitk), nk = (int)((long)nk_all * (blockIdx.y + 1) / g.splitk);
@@ -181,9 +180,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     // weight fragment as the A operand: the accumulator is C^T (common.h, epilogue_tile32)
-                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], accm[i][j], 0, 0, 0);
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], accx[i][j], 0, 0, 0);
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], accx[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
                 }
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
@@ -197,8 +196,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) accm[i][j][e] += accx[i][j][e] * kLoInv;
-                partial_tile32(g, P, m0 + wm * (BM / WM) + i * 32 + r, n0 + wn * (BN / WN) + j * 32, h, accm[i][j]);
+                for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
+                partial_tile32(g, P, m0 + wm * (BM / WM) + i * 32 + r, n0 + wn * (BN / WN) + j * 32, h, acc[i][j]);
             }
         return;
     }
@@ -208,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) accm[i][j][e] += accx[i][j][e] * kLoInv;
-            epilogue_tile32(g, epi, m0 + wm * (BM / WM) + i * 32 + r, n0 + wn * (BN / WN) + j * 32, h, accm[i][j]);
+            for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
+            epilogue_tile32(g, epi, m0 + wm * (BM / WM) + i * 32 + r, n0 + wn * (BN / WN) + j * 32, h, acc[i][j]);
         }
 }
 
@@ -339,13 +338,13 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
             }
     }
 
-    f32x16 accm[2][TN], accx[2][TN];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { accm[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = g.K / BK;
 #pragma unroll
@@ -376,10 +375,11 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
     };
     constexpr int NMF = 2 * TN * 3;    // MFMAs per half step
     auto mfma_slot = [&](int sidx, const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
-        const int i = sidx / (3 * TN), j = (sidx / 3) % TN, t = sidx % 3;     // weight fragment = A operand: C^T, see epilogue_tile32
-        if (t == 0) accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], accm[i][j], 0, 0, 0);
-        else if (t == 1) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], accx[i][j], 0, 0, 0);
-        else accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], accx[i][j], 0, 0, 0);
+        // term-major order: consecutive MFMAs go to different accumulators.  Weight fragment = A operand: C^T, see epilogue_tile32
+        const int t = sidx / (2 * TN), i = (sidx / TN) % 2, j = sidx % TN;
+        if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
     };
     auto mfmas = [&](const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
 #pragma unroll
@@ -441,11 +441,20 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) accm[i][j][e] += accx[i][j][e] * kLoInv;
-            epilogue_tile32(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * (32 * TN) + j * 32, h, accm[i][j]);
-        }
+            for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
+    if (epi.vec) {      // coalesced: transpose through this wave's slice of the (now idle) stage ring
+        __builtin_amdgcn_s_barrier();      // every wave has consumed its last fragments
+        constexpr int SLICE = 64 * (32 * TN + 4);
+        static_assert(8 * SLICE * 4 <= STAGES * STAGE_BYTES, "epilogue LDS");
+        epilogue_wave_lds<2, TN>(g, epi, reinterpret_cast<float*>(smem_p8) + wave * SLICE, m0 + wm * 64, n0 + wn * (32 * TN), lane, acc);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) epilogue_tile32(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * (32 * TN) + j * 32, h, acc[i][j]);
+    }
     if constexpr (ABL == 6) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -453,16 +462,408 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
     }
 }
 
-void launch_gemm_p8(const GemmArgs& g, hipStream_t s) {
-    if (g.M <= 0 || g.N <= 0) return;
+// ------------------------------------------------------------------------------------------------------------------
+// 256x256 tile variant of the LDS-DMA kernel.  The 128x128 kernel above is bound by what the LDS-DMA path of a CU delivers
+// (~60 GB/s: 32 KiB per K step in 0.53 us with the MFMAs removed, 0.68 us with them); a 256x256 tile needs half the operand
+// bytes per flop, which one fp32 accumulator per output (common.h: both operand halves share a scale) makes affordable:
+// 8 waves as 2 x 4, wave tile 128 x 64 = 4 x 2 MFMA tiles = 128 accumulator registers.
+//   LDS: 2 stages of 64 KiB (A 256 rows x 128 B, then W 256 rows x 128 B, same XOR swizzle as above).  One K step (32 deep)
+//   is 48 MFMAs per wave (~1.5 us per CU), long enough that a two-stage ring covers the L2/HBM latency:
+//     top of K step kt:  vmcnt(0) (stage kt, issued during step kt-1, has landed for this wave) + ONE barrier (landed for
+//                        all waves, and all waves are done reading stage kt-1, whose buffer is refilled next)
+//     body:              the 8 DMA pieces of stage kt+1 go out one per two MFMAs at the start of the step;
+//                        fragments roll through registers: B fragments of a k block (2 tiles) are double buffered, A tiles
+//                        (4 per k block) stream through two slots, each read issued 6 MFMAs before its first use and
+//                        waited for with a counted lgkmcnt.
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 32;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;     // 64 KiB
+    constexpr int NDMA = 8;                           // 1-KiB pieces per wave per stage: 4 of A, 4 of W
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
+
+    const int tid = threadIdx.x;
+    unsigned long long* stamps = nullptr;
+    if constexpr (ABL == 6) {
+        stamps = reinterpret_cast<unsigned long long*>(g.partial) + (long)blockIdx.x * 8;
+        if (tid == 0) {
+            stamps[0] = wall_clock64();
+            stamps[4] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+            stamps[5] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+        }
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // Start stagger: all CUs of an XCD would otherwise reach their epilogues together and the 8 MiB burst (32 x 256 KiB) drains at
+    // the XCD's ~250 GB/s write link (33 us per tile measured); spreading the first round's start times inside each XCD lets the
+    // 4 MiB L2 absorb the stores of the few CUs that are in their epilogue at any one time.
+    if (g.stagger_ticks > 0 && blockIdx.x < 256) {
+        const unsigned long long t0 = wall_clock64();
+        const unsigned long long d = (unsigned long long)((blockIdx.x >> 3) & 31) * g.stagger_ticks / 32;
+        while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(16);
+    }
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    int tm, tn;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GM = 2;
+        const int width = GM * tiles_n;
+        const int group = idx / width, first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        const int in_g = idx - group * width;
+        tn = in_g / gsz;
+        tm = first_m + (in_g - tn * gsz);
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- DMA addressing: piece = 8 rows x 128 B; wave w owns A rows 32w..32w+31 and W rows 32w..32w+31 of the tile ----
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const unsigned char* src[NDMA];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ra = wave * 32 + q * 8 + prow;
+        const int gm = min(m0 + ra, g.M - 1);          // clamp: rows >= M are never stored
+        const int gn = min(n0 + ra, g.N - 1);
+        const int sw = (pchunk ^ ((ra >> 1) & 7)) << 4;
+        src[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda) * 4 + sw;
+        src[4 + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw) * 4 + sw;
+    }
+    auto issue_piece = [&](int q, int kt, int buf) {
+        unsigned char* dst = smem_p8 + buf * STAGE_BYTES + (q < 4 ? 0 : BM * 128) + (wave * 4 + (q & 3)) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (long)kt * (BK * 4)),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_p8;
+    unsigned a_off[2][2], w_off[2][2];               // [kb][hi/lo]; further tiles are +4096 B per 32 rows (same swizzle key)
+    {
+        const int arow = wm * 128 + r, wrow = wn * 64 + r;
+        const int akey = (arow >> 1) & 7, wkey = (wrow >> 1) & 7;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int lo = 0; lo < 2; ++lo) {
+                const int c = (kb * 2 + h) * 2 + lo;
+                a_off[kb][lo] = lds0 + arow * 128 + ((c ^ akey) << 4);
+                w_off[kb][lo] = lds0 + BM * 128 + wrow * 128 + ((c ^ wkey) << 4);
+            }
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = g.K / BK;
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) issue_piece(q, 0, 0);
+
+    f16x8 bh[2][2], bl[2][2];      // [k block parity][n tile]
+    f16x8 ah[2], al[2];            // two slots, m tile i lives in slot i & 1
+    auto read_b = [&](unsigned sb, int kb) {
+        bh[kb][0] = lds_read128<0>(w_off[kb][0] + sb);
+        bl[kb][0] = lds_read128<0>(w_off[kb][1] + sb);
+        bh[kb][1] = lds_read128<4096>(w_off[kb][0] + sb);
+        bl[kb][1] = lds_read128<4096>(w_off[kb][1] + sb);
+    };
+    auto read_a = [&](unsigned sb, int kb, int i) {
+        const unsigned hp = a_off[kb][0] + sb, lp = a_off[kb][1] + sb;
+        if (i == 0) { ah[0] = lds_read128<0>(hp); al[0] = lds_read128<0>(lp); }
+        else if (i == 1) { ah[1] = lds_read128<4096>(hp); al[1] = lds_read128<4096>(lp); }
+        else if (i == 2) { ah[0] = lds_read128<8192>(hp); al[0] = lds_read128<8192>(lp); }
+        else { ah[1] = lds_read128<12288>(hp); al[1] = lds_read128<12288>(lp); }
+    };
+    // one K step from ring buffer `buf`; ISSUE: fetch stage kt+1 into the other buffer meanwhile.  The eight (k block, m tile)
+    // sub-steps are spelled out with compile-time indices (fragment slots and DMA pieces are register arrays).
+    const int dma_kb = g.dma_split ? wm : 0;       // tuning: the two waves of a SIMD (w, w+4) issue their DMA in different halves of the step
+    auto substep = [&](int kt, int buf, unsigned sb, auto issue_tag, auto kb_tag, auto i_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        constexpr int kb = decltype(kb_tag)::value, i = decltype(i_tag)::value;
+        // prefetch the next fragments, then wait for everything older than them
+        if constexpr (i < 3) { read_a(sb, kb, i + 1); wait_lgkmcnt<2>(); }
+        else if constexpr (kb == 0) { read_b(sb, 1); read_a(sb, 1, 0); wait_lgkmcnt<6>(); }
+        else wait_lgkmcnt<0>();
+        constexpr int sl = i & 1;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], ah[sl], acc[i][j], 0, 0, 0);
+                else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kb][j], ah[sl], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], al[sl], acc[i][j], 0, 0, 0);
+                const int piece = i * 3 + t;     // one DMA piece per two MFMAs over the first 16 MFMAs of the step
+                if (ISSUE && kb == dma_kb && j == 1 && piece < NDMA) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_piece(piece, kt + 1, buf ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto kstep = [&](int kt, int buf, auto issue_tag) {
+        const unsigned sb = buf * STAGE_BYTES;
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(sb, 0);
+        read_a(sb, 0, 0);
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        substep(kt, buf, sb, issue_tag, I0{}, I0{});
+        substep(kt, buf, sb, issue_tag, I0{}, I1{});
+        substep(kt, buf, sb, issue_tag, I0{}, I2{});
+        substep(kt, buf, sb, issue_tag, I0{}, I3{});
+        substep(kt, buf, sb, issue_tag, I1{}, I0{});
+        substep(kt, buf, sb, issue_tag, I1{}, I1{});
+        substep(kt, buf, sb, issue_tag, I1{}, I2{});
+        substep(kt, buf, sb, issue_tag, I1{}, I3{});
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; ++kt) {
+        if (ABL == 6 && kt == 1) { if (tid == 0) stamps[1] = wall_clock64(); }
+        kstep(kt, kt & 1, std::true_type{});
+    }
+    kstep(kt, kt & 1, std::false_type{});
+    if constexpr (ABL == 6) { if (tid == 0) stamps[2] = wall_clock64(); }
+
+    const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+    if (epi.vec) {      // coalesced: two passes (m tiles 0-1, then 2-3) through this wave's 17 KiB slice of LDS
+        __builtin_amdgcn_s_barrier();      // every wave has consumed its last fragments
+        constexpr int SLICE = 64 * 68;
+        float* lds = reinterpret_cast<float*>(smem_p8) + wave * SLICE;
+        f32x16 (&lo2)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[0]);
+        f32x16 (&hi2)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
+        epilogue_wave_lds<2, 2>(g, epi, lds, m0 + wm * 128, n0 + wn * 64, lane, lo2);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        epilogue_wave_lds<2, 2>(g, epi, lds, m0 + wm * 128 + 64, n0 + wn * 64, lane, hi2);
+    } else {
+        auto epi_tile = [&](auto i_tag, auto j_tag) {
+            constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
+            epilogue_tile32(g, epi, m0 + wm * 128 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        epi_tile(I0{}, I0{}); epi_tile(I0{}, I1{}); epi_tile(I1{}, I0{}); epi_tile(I1{}, I1{});
+        epi_tile(I2{}, I0{}); epi_tile(I2{}, I1{}); epi_tile(I3{}, I0{}); epi_tile(I3{}, I1{});
+    }
+    if constexpr (ABL == 6) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) stamps[3] = wall_clock64();
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Two-workgroups-per-CU variant: 128x128 tile, 4 waves (2 x 2, wave tile 64 x 64 = 64 accumulator registers), 2 stages of
+// 32 KiB = 64 KiB of LDS per workgroup, so two workgroups are co-resident on a CU and run out of phase: while one sits in its
+// epilogue (a tile's 64 KiB of stores drain in ~3.6 us whatever their shape: the write path, not instruction issue, bounds
+// them), in its prologue, at its barrier or waiting for a DMA stage, the other one owns the matrix cores.  Same two-stage
+// K-step structure as the 256x256 kernel: vmcnt(0) + one barrier at the top of a step, the 8 DMA pieces of the next stage
+// issued in the MFMA gaps of this one, fragments rolling through registers behind counted lgkmcnt waits.
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;     // 32 KiB
+    constexpr int NDMA = 8;                           // 1-KiB pieces per wave per stage: 4 of A, 4 of W
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
+
+    const int tid = threadIdx.x;
+    unsigned long long* stamps = nullptr;
+    if constexpr (ABL == 6) {
+        stamps = reinterpret_cast<unsigned long long*>(g.partial) + (long)blockIdx.x * 8;
+        if (tid == 0) {
+            stamps[0] = wall_clock64();
+            stamps[4] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+            stamps[5] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+        }
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    int tm, tn;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GM = 4;
+        const int width = GM * tiles_n;
+        const int group = idx / width, first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        const int in_g = idx - group * width;
+        tn = in_g / gsz;
+        tm = first_m + (in_g - tn * gsz);
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- DMA addressing: piece = 8 rows x 128 B; wave w owns A rows 32w..32w+31 and W rows 32w..32w+31 of the tile ----
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const unsigned char* src[NDMA];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ra = wave * 32 + q * 8 + prow;
+        const int gm = min(m0 + ra, g.M - 1);          // clamp: rows >= M are never stored
+        const int gn = min(n0 + ra, g.N - 1);
+        const int sw = (pchunk ^ ((ra >> 1) & 7)) << 4;
+        src[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda) * 4 + sw;
+        src[4 + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw) * 4 + sw;
+    }
+    auto issue_piece = [&](int q, int kt, int buf) {
+        unsigned char* dst = smem_p8 + buf * STAGE_BYTES + (q < 4 ? 0 : BM * 128) + (wave * 4 + (q & 3)) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (long)kt * (BK * 4)),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_p8;
+    unsigned a_off[2][2], w_off[2][2];               // [kb][hi/lo]; the second tile is +4096 B (32 rows, same swizzle key)
+    {
+        const int arow = wm * 64 + r, wrow = wn * 64 + r;
+        const int akey = (arow >> 1) & 7, wkey = (wrow >> 1) & 7;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int lo = 0; lo < 2; ++lo) {
+                const int c = (kb * 2 + h) * 2 + lo;
+                a_off[kb][lo] = lds0 + arow * 128 + ((c ^ akey) << 4);
+                w_off[kb][lo] = lds0 + BM * 128 + wrow * 128 + ((c ^ wkey) << 4);
+            }
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = g.K / BK;
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) issue_piece(q, 0, 0);
+
+    f16x8 bh[2][2], bl[2][2];      // [k block parity][n tile]
+    f16x8 ah[2], al[2];            // [m tile]
+    auto read_b = [&](unsigned sb, int kb) {
+        bh[kb][0] = lds_read128<0>(w_off[kb][0] + sb);
+        bl[kb][0] = lds_read128<0>(w_off[kb][1] + sb);
+        bh[kb][1] = lds_read128<4096>(w_off[kb][0] + sb);
+        bl[kb][1] = lds_read128<4096>(w_off[kb][1] + sb);
+    };
+    auto read_a = [&](unsigned sb, int kb, int i) {
+        const unsigned hp = a_off[kb][0] + sb, lp = a_off[kb][1] + sb;
+        if (i == 0) { ah[0] = lds_read128<0>(hp); al[0] = lds_read128<0>(lp); }
+        else { ah[1] = lds_read128<4096>(hp); al[1] = lds_read128<4096>(lp); }
+    };
+    auto substep = [&](int kt, int buf, unsigned sb, auto issue_tag, auto kb_tag, auto i_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        constexpr int kb = decltype(kb_tag)::value, i = decltype(i_tag)::value;
+        if constexpr (i == 0) { read_a(sb, kb, 1); wait_lgkmcnt<2>(); }
+        else if constexpr (kb == 0) { read_b(sb, 1); read_a(sb, 1, 0); wait_lgkmcnt<6>(); }
+        else wait_lgkmcnt<0>();
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], ah[i], acc[i][j], 0, 0, 0);
+                else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kb][j], ah[i], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], al[i], acc[i][j], 0, 0, 0);
+                const int piece = (kb * 2 + i) * 3 + t;     // one DMA piece per two MFMAs over the first 16 MFMAs of the step
+                if (ISSUE && j == 1 && piece < NDMA) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_piece(piece, kt + 1, buf ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto kstep = [&](int kt, int buf, auto issue_tag) {
+        const unsigned sb = buf * STAGE_BYTES;
+        wait_vmcnt<0>();                                   // stage kt (issued during step kt-1) landed for this wave
+        __builtin_amdgcn_s_barrier();                      // ... for all waves, and all are done reading stage kt-1
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(sb, 0);
+        read_a(sb, 0, 0);
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        substep(kt, buf, sb, issue_tag, I0{}, I0{});
+        substep(kt, buf, sb, issue_tag, I0{}, I1{});
+        substep(kt, buf, sb, issue_tag, I1{}, I0{});
+        substep(kt, buf, sb, issue_tag, I1{}, I1{});
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; ++kt) {
+        if (ABL == 6 && kt == 1) { if (tid == 0) stamps[1] = wall_clock64(); }
+        kstep(kt, kt & 1, std::true_type{});
+    }
+    kstep(kt, kt & 1, std::false_type{});
+    if constexpr (ABL == 6) { if (tid == 0) stamps[2] = wall_clock64(); }
+
+    const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+    auto epi_tile = [&](auto i_tag, auto j_tag) {
+        constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
+        epilogue_tile32(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);
+    };
+    {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        epi_tile(I0{}, I0{}); epi_tile(I0{}, I1{}); epi_tile(I1{}, I0{}); epi_tile(I1{}, I1{});
+    }
+    if constexpr (ABL == 6) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) stamps[3] = wall_clock64();
+    }
+}
+
+
+int gemm_p8_variant(const GemmArgs& g);
+void launch_gemm_p8(const GemmArgs& g_in, hipStream_t s) {
+    if (g_in.M <= 0 || g_in.N <= 0) return;
+    GemmArgs g = g_in;
+    {   // tuning knobs of the 256x256 kernel (environment, read once)
+        static const int stagger_us = getenv("ARTALK_P8_STAGGER_US") ? atoi(getenv("ARTALK_P8_STAGGER_US")) : 0;
+        static const int dma_split = getenv("ARTALK_P8_DMA_SPLIT") ? atoi(getenv("ARTALK_P8_DMA_SPLIT")) : 0;
+        g.stagger_ticks = stagger_us * 100;
+        g.dma_split = dma_split;
+    }
     const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t256 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
-    switch (g.force_cfg) {   // tuning: 3 / 5 = pipeline depth of the 128x128 kernel, 6 = 256x128 tiles (3 stages of 48 KiB)
+    const int t256sq = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    int cfg = g.force_cfg;
+    if (cfg < 0) cfg = gemm_p8_variant(g) == 1 ? 7 : 8;
+    switch (cfg) {   // 7 / 8 are the production kernels; the others are kept for tuning (tools/gemm_f16s_bench.py)
+        case 2: hipLaunchKernelGGL((gemm_p8_kernel<128, 4>), dim3(t128), dim3(512), 4 * 256 * 128, s, g); break;
         case 3: hipLaunchKernelGGL((gemm_p8_kernel<128, 3>), dim3(t128), dim3(512), 3 * 256 * 128, s, g); break;
         case 5: hipLaunchKernelGGL((gemm_p8_kernel<128, 5>), dim3(t128), dim3(512), 5 * 256 * 128, s, g); break;
         case 6: hipLaunchKernelGGL((gemm_p8_kernel<256, 3>), dim3(t256), dim3(512), 3 * 384 * 128, s, g); break;
         case 16: hipLaunchKernelGGL((gemm_p8_kernel<128, 4, 6>), dim3(t128), dim3(512), 4 * 256 * 128, s, g); break;
-        default: hipLaunchKernelGGL((gemm_p8_kernel<128, 4>), dim3(t128), dim3(512), 4 * 256 * 128, s, g); break;
+        case 7: hipLaunchKernelGGL((gemm_p8_256_kernel<0>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
+        case 17: hipLaunchKernelGGL((gemm_p8_256_kernel<6>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
+        case 18: hipLaunchKernelGGL((gemm_p8_2wg_kernel<6>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;
+        default: hipLaunchKernelGGL((gemm_p8_2wg_kernel<0>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;
     }
+}
+// 0: two-workgroup 128x128 kernel (default), 1: 256x256 kernel.  The big tile halves the operand bytes per flop but its 256 KiB
+// epilogue is not overlapped and its grid is four times coarser: it wins once the grid is >= 10 rounds deep (the conv stack and the
+// AdaLN table: 354 vs 329 and 330 vs 306 TF/s), loses on the encoder GEMMs (profiles/r01_gemm_f16s_bench.log).
+int gemm_p8_variant(const GemmArgs& g) {
+    const long t256sq = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+    return (t256sq >= 2560 && g.N % 256 == 0) ? 1 : 0;
 }
 bool gemm_p8_eligible(const GemmArgs& g) {
     return g.Wp != nullptr && g.a_packed && g.amode == 0 && g.batch == 1 && g.splitk == 1 && g.K % 32 == 0 && (g.lda % 8) == 0 &&

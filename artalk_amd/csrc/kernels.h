@@ -47,17 +47,19 @@ struct GemmArgs {
     int splitk = 1; float* partial = nullptr;
     int force_cfg = -1;  // >= 0: tile configuration override (tuning/tests)
     int graph_tag = 0;   // 1 for launches inside the captured AR/VAE body (separate kernel symbol, same code)
+    int stagger_ticks = 0, dma_split = 0;   // gemm_p8_256_kernel tuning (launch_gemm_p8)
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);
 void launch_splitk_reduce(const GemmArgs& g, hipStream_t s);   // epilogue pass of a split-K GEMM (g.splitk > 1)
 int gemm_tile_count(const GemmArgs& g, bool f16s);             // output tiles of the configuration launch_gemm[_f16s] would pick
 // fp32-accurate GEMM on the fp16 matrix cores by operand splitting (gemm_f16s.hip)
-void launch_pack_split(const float* w, unsigned int* out, long n, hipStream_t s);
+void launch_pack_split(const float* w, unsigned int* out, long n, bool is_weight, hipStream_t s);
 bool gemm_f16s_eligible(const GemmArgs& g);
 int gemm_f16s_config(const GemmArgs& g);     // 0: 128x128 (dominant kernel of the split mode), 1: 64x64
 void launch_gemm_f16s(const GemmArgs& g, hipStream_t s);
 bool gemm_p8_eligible(const GemmArgs& g);      // both operands in P8 and a large grid: LDS-DMA pipelined kernel
 void launch_gemm_p8(const GemmArgs& g, hipStream_t s);
+int gemm_p8_variant(const GemmArgs& g);        // 0: gemm_p8_2wg_kernel (128x128, two workgroups per CU), 1: gemm_p8_256_kernel
 int gemm_config(const GemmArgs& g);   // 4: 128x128 BK16 (dominant kernel), 2: 64x64, 1: 128x64, 3: 32x128; 0,5,6,7 tuning variants
 // Average kernel time helper for benches: FLOPs of one launch
 static inline double gemm_flops(const GemmArgs& g) { return 2.0 * g.M * (double)g.N * g.K * g.batch; }

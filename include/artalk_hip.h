@@ -147,7 +147,7 @@ int artalk_op_mfma_f32_peak(float* out_dev, int blocks, int iters, int nacc, dou
 int artalk_op_gemm_f16s(const float* A, int64_t lda, const float* W, const float* bias, float* C, int M, int N, int K, int act,
                         int force_cfg, void* stream);
 /* tuning helpers: fp32 -> packed split words; split GEMM on pre-packed W (and optionally pre-packed A) */
-int artalk_op_pack_split(const float* in, void* out_u32, int64_t n, void* stream);
+int artalk_op_pack_split(const float* in, void* out_u32, int64_t n, int is_weight, void* stream);   /* operand scale: 0 activation, 1 weight */
 int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const void* Wp, const float* bias, float* C, int M, int N,
                                int K, int act, int force_cfg, void* stream);
 /* y = LN(x)[*w+b][*(1+scale)+shift][act], D in {128,512,768,1024}; act | 0x100 writes y in the P8 split format */

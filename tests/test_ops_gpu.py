@@ -89,7 +89,8 @@ def test_gemm_f16x3_split_is_fp32_accurate(M, N, K, cfg):
     err = (out.cpu().double() - ref).abs().max().item() / scale
     err32 = (out32.cpu().double() - ref).abs().max().item() / scale
     print(f"f16x3 rel err {err:.2e}  fp32-mfma rel err {err32:.2e}")
-    assert err < 1.5e-6 and err < 4 * err32 + 2e-7, (err, err32)
+    # bar: no worse than the exact-fp32 MFMA kernel's own accumulation rounding (one fp32 accumulator per output in both)
+    assert err < 3e-6 and err < 1.25 * err32 + 2e-7, (err, err32)
 
 
 def test_gemm_p8_dma_pipeline_and_producers():
@@ -107,16 +108,16 @@ def test_gemm_p8_dma_pipeline_and_producers():
     dX, dlw, dlb, dW, db = _dev(X), _dev(lw), _dev(lb), _dev(W), _dev(bias)
     Ap = torch.empty(M, K, dtype=torch.int32, device="cuda")     # P8 has the fp32 pitch
     Wp = torch.empty(N, K, dtype=torch.int32, device="cuda")
-    assert L.artalk_op_pack_split(_p(dW), _p(Wp), N * K, None) == 0
+    assert L.artalk_op_pack_split(_p(dW), _p(Wp), N * K, 1, None) == 0
     # LayerNorm -> P8 (flag in the high bits of `act`: see artalk_op_layernorm)
     assert L.artalk_op_layernorm(_p(dX), _p(Ap), _p(dlw), _p(dlb), None, None, M, K, 1e-5, 0x100, None) == 0
     out = torch.full((M, N), float("nan"), device="cuda")
-    for cfg in (2, 0, 1):       # DMA pipeline, register-staged 128x128 and 64x64, all fed with the P8 activation
+    for cfg in (2, 7, 8, 6, 0, 1):  # DMA pipeline 128x128 / 256x256 / 256x128, register-staged 128x128 and 64x64, all fed with the P8 activation
         out.fill_(float("nan"))
         assert L.artalk_op_gemm_f16s_packed(_p(Ap), 1, K, _p(Wp), _p(db), _p(out), M, N, K, 0, cfg, None) == 0
         torch.cuda.synchronize()
         err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
-        assert err < 1.5e-6, (cfg, err)
+        assert err < 2e-6, (cfg, err)
 
 
 def test_gemm_exact_integers():

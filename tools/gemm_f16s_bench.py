@@ -19,7 +19,7 @@ s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for name, M, N, K in SHAPES:
     A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.03; b = torch.randn(N, device="cuda")
     Ap = torch.empty(M, K, dtype=torch.int32, device="cuda"); Wp = torch.empty(N, K, dtype=torch.int32, device="cuda")
-    L.artalk_op_pack_split(p(A), p(Ap), M * K, s); L.artalk_op_pack_split(p(W), p(Wp), N * K, s)
+    L.artalk_op_pack_split(p(A), p(Ap), M * K, 0, s); L.artalk_op_pack_split(p(W), p(Wp), N * K, 1, s)
     Cc = torch.empty(M, N, device="cuda")
     ref = A[:256].double() @ W.double().t() + b.double()
     line = f"{name:12s} M={M:6d} N={N:5d} K={K:4d} "

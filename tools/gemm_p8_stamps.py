@@ -11,15 +11,17 @@ L = capi.lib()
 p = lambda t: C.c_void_p(t.data_ptr())
 SHAPES = [("w2v out", 19200, 1024, 1024), ("w2v ff1", 19200, 4096, 1024), ("w2v ff2", 19200, 1024, 4096), ("K=256", 19200, 1024, 256)]
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+CFG = int(os.environ.get("STAMP_CFG", "16"))      # 16: 128x128 kernel, 17: 256x256 kernel, 18: two-workgroup 128x128 kernel
+T = 256 if CFG == 17 else 128
 for name, M, N, K in SHAPES:
     A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.03
     Ap = torch.empty(M, K, dtype=torch.int32, device="cuda"); Wp = torch.empty(N, K, dtype=torch.int32, device="cuda")
-    L.artalk_op_pack_split(p(A), p(Ap), M * K, s); L.artalk_op_pack_split(p(W), p(Wp), N * K, s)
+    L.artalk_op_pack_split(p(A), p(Ap), M * K, 0, s); L.artalk_op_pack_split(p(W), p(Wp), N * K, 1, s)
     Cc = torch.empty(M, N, device="cuda")
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    tiles = ((M + T - 1) // T) * ((N + T - 1) // T)
     st = torch.zeros(tiles, 8, dtype=torch.int64, device="cuda")
     for _ in range(3):
-        assert L.artalk_op_gemm_f16s_packed(p(Ap), 1, K, p(Wp), p(st), p(Cc), M, N, K, 0, 16, s) == 0
+        assert L.artalk_op_gemm_f16s_packed(p(Ap), 1, K, p(Wp), p(st), p(Cc), M, N, K, 0, CFG, s) == 0
     torch.cuda.synchronize()
     t = st.cpu().numpy()
     us = lambda x: x / 100.0                       # 100 MHz counter
