@@ -371,7 +371,10 @@ void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
     if (m->profiling && dominant) next_event(m, s, &i0);
     if (g.a_packed && !split) { m->err = "internal: P8 activation handed to an fp32 GEMM"; m->sticky_error = true; return; }
     const bool dma = split && g.splitk == 1 && gemm_p8_eligible(g);
-    if (dma) launch_gemm_p8(g, s); else if (split) launch_gemm_f16s(g, s); else launch_gemm(g, s);
+    if (dma) launch_gemm_p8(g, s);
+    else if (split && gemm_p8_sm_eligible(g)) launch_gemm_p8_sm(g, s);     // P8 activation, small grid (AR/VAE scale steps)
+    else if (split) launch_gemm_f16s(g, s);
+    else launch_gemm(g, s);
     if (g.splitk > 1) launch_splitk_reduce(g, s);
     if (m->profiling && dominant) {
         next_event(m, s, &i1);
@@ -532,6 +535,9 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
     Workspace& w = m->view ? *m->view : m->ws;
     const long ldada = m->ada_n;
     const long cache_l = (long)w.maxB * 2 * kNTok * 3 * kE;   // floats per layer
+    // f16x3 mode: the block's GEMM-only activations (modulated LN output, attention output, FFN hidden) are written in the P8 split
+    // format by their producers, which lets every block GEMM use the LDS-DMA kernels (gemm_p8_sm_kernel at these grid sizes)
+    const int p8 = m->precision == 1 ? 1 : 0;
     // K/V of the 181 history tokens, once per layer (raw prev tokens, not modulated: app/transformer.py:68-70)
     for (int l = 0; l < c.ar_depth; ++l) {
         const ARLayer& L = m->ar[l];
@@ -551,30 +557,30 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
             float* cache = w.cache + l * cache_l;
             LnArgs n1;
             n1.X = w.x; n1.ldx = kE; n1.Y = w.xmod; n1.ldy = kE; n1.scale = ada + 2 * kE; n1.shift = ada + 4 * kE; n1.ldm = ldada;
-            n1.mmap = amap; n1.M = M; n1.D = kE; n1.eps = 1e-6f;
+            n1.mmap = amap; n1.M = M; n1.D = kE; n1.eps = 1e-6f; n1.out_p8 = p8;
             launch_layernorm(n1, s);
             GemmArgs q;
             q.A = w.xmod; q.lda = kE; q.W = L.qkv_w; q.ldw = kE; q.bias = L.qkv_b; q.C = cache; q.ldc = 3 * kE;
-            q.cmap = rowmap(pn, 2 * kNTok, kNTok + off); q.M = M; q.N = 3 * kE; q.K = kE;
+            q.cmap = rowmap(pn, 2 * kNTok, kNTok + off); q.M = M; q.N = 3 * kE; q.K = kE; q.a_packed = p8;
             gemm(m, q, s);
             AttnArgs a;
             a.Q = cache + (long)(kNTok + off) * 3 * kE; a.K = cache + kE; a.V = cache + 2 * kE;
             a.ldq = a.ldk = a.ldv = 3 * kE; a.q_bstride = a.k_bstride = a.v_bstride = (long)2 * kNTok * 3 * kE;
             a.O = w.attn_out; a.ldo = kE; a.o_bstride = (long)pn * kE;
             a.B = B; a.H = c.ar_heads; a.HD = kE / c.ar_heads; a.Lq = pn; a.Lk = kNTok + off + pn; a.scale = 1.0f;
-            a.l2norm = 1; a.qscale = L.qscale;
+            a.l2norm = 1; a.qscale = L.qscale; a.out_p8 = p8;
             launch_attention(a, s);
             GemmArgs pj;
             pj.A = w.attn_out; pj.lda = kE; pj.W = L.proj_w; pj.ldw = kE; pj.bias = L.proj_b; pj.C = w.x; pj.ldc = kE;
-            pj.gate = ada; pj.ldg = ldada; pj.gmap = amap; pj.R = w.x; pj.ldr = kE; pj.M = M; pj.N = kE; pj.K = kE;
+            pj.gate = ada; pj.ldg = ldada; pj.gmap = amap; pj.R = w.x; pj.ldr = kE; pj.M = M; pj.N = kE; pj.K = kE; pj.a_packed = p8;
             gemm(m, pj, s);
             LnArgs n2 = n1;
             n2.scale = ada + 3 * kE; n2.shift = ada + 5 * kE;
             launch_layernorm(n2, s);
-            linear(m, w.xmod, kE, L.ffn1_w, L.ffn1_b, w.ffn_h, 4 * kE, M, 4 * kE, kE, ACT_GELU_TANH, nullptr, s);
+            linear(m, w.xmod, kE, L.ffn1_w, L.ffn1_b, w.ffn_h, 4 * kE, M, 4 * kE, kE, ACT_GELU_TANH, nullptr, s, p8 ? (LF_A_P8 | LF_C_P8) : 0);
             GemmArgs f2;
             f2.A = w.ffn_h; f2.lda = 4 * kE; f2.W = L.ffn2_w; f2.ldw = 4 * kE; f2.bias = L.ffn2_b; f2.C = w.x; f2.ldc = kE;
-            f2.gate = ada + kE; f2.ldg = ldada; f2.gmap = amap; f2.R = w.x; f2.ldr = kE; f2.M = M; f2.N = kE; f2.K = 4 * kE;
+            f2.gate = ada + kE; f2.ldg = ldada; f2.gmap = amap; f2.R = w.x; f2.ldr = kE; f2.M = M; f2.N = kE; f2.K = 4 * kE; f2.a_packed = p8;
             gemm(m, f2, s);
         }
         // head (app/models.py:145-148,103): scale, shift = split2
@@ -1206,7 +1212,23 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
         if (!a_packed) return ARTALK_EINVAL;
         g.force_cfg = force_cfg == 9 ? -1 : force_cfg;   // 9: the engine's own choice between the production kernels (7 / 8)
         if (force_cfg >= 16 && force_cfg <= 18) { g.partial = (float*)bias; g.bias = nullptr; }   // timing build: `bias` carries the stamp buffer (8 x u64 per tile)
-        launch_gemm_p8(g, (hipStream_t)stream);
+        if ((force_cfg & 0xff) >= 20) {     // 20-22: small-grid LDS-DMA kernel; bits 8-15: split-K factor (slabs in a temporary)
+            g.force_cfg = force_cfg & 0xff;
+            const int S = (force_cfg >> 8) & 0xff;
+            float* part = nullptr;
+            if (S > 1) {
+                if (hipMalloc(&part, (size_t)S * M * N * 4) != hipSuccess) return ARTALK_EHIP;
+                g.splitk = S; g.partial = part;
+            }
+            launch_gemm_p8_sm(g, (hipStream_t)stream);
+            if (S > 1) {
+                launch_splitk_reduce(g, (hipStream_t)stream);
+                (void)hipStreamSynchronize((hipStream_t)stream);
+                (void)hipFree(part);
+            }
+        } else {
+            launch_gemm_p8(g, (hipStream_t)stream);
+        }
     } else {
         launch_gemm_f16s(g, (hipStream_t)stream);
     }

@@ -832,6 +832,208 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------
+// Small-grid variant for the AR/VAE scale steps (M = clips x 1..100 tokens): these launches are bound by the latency of ONE
+// tile, and the register-staged kernel's single K tile of prefetch costs ~1 us per K step (a 64x64 tile over K = 768 took
+// 23-28 us whatever M was).  Here a 64x64 (or 128x64) tile is fed by the same LDS-DMA ring as the big kernels, STAGES-1 K
+// tiles in flight, 4 waves (2 x 2), split-K over blockIdx.y with the partial slabs of gemm_f32.hip.
+template <int BM, int BN, int STAGES, int TAG>
+__global__ __launch_bounds__(256) void gemm_p8_sm_kernel(const GemmArgs g) {
+    constexpr int BK = 32;
+    constexpr int TM = BM / 64, TN = BN / 64;              // 32x32 MFMA tiles per wave
+    constexpr int APIECES = BM / 32, WPIECES = BN / 32;    // 1-KiB DMA pieces per wave per stage
+    constexpr int NDMA = APIECES + WPIECES;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int NRD = 2 * TM + 2 * TN, NMF = 3 * TM * TN;
+    static_assert(STAGES >= 3 && STAGES * STAGE_BYTES <= 160 * 1024, "LDS");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    int tm, tn;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GM = 8;
+        const int width = GM * tiles_n;
+        const int group = idx / width, first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        const int in_g = idx - group * width;
+        tn = in_g / gsz;
+        tm = first_m + (in_g - tn * gsz);
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk_all = g.K / BK;   // split-K: this workgroup owns K tiles [kt0, kt0 + nk)
+    const int kt0 = (int)((long)nk_all * blockIdx.y / g.splitk);
+    const int nk = (int)((long)nk_all * (blockIdx.y + 1) / g.splitk) - kt0;
+
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const unsigned char* src[NDMA];
+#pragma unroll
+    for (int q = 0; q < APIECES; ++q) {
+        const int ra = (wave * APIECES + q) * 8 + prow;
+        const int gm = min(m0 + ra, g.M - 1);
+        src[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda + (long)kt0 * BK) * 4 + ((pchunk ^ ((ra >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int q = 0; q < WPIECES; ++q) {
+        const int rw = (wave * WPIECES + q) * 8 + prow;
+        const int gn = min(n0 + rw, g.N - 1);
+        src[APIECES + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw + (long)kt0 * BK) * 4 + ((pchunk ^ ((rw >> 1) & 7)) << 4);
+    }
+    auto issue_piece = [&](int q, int kt, int buf) {
+        unsigned char* dst = smem_p8 + buf * STAGE_BYTES +
+                             (q < APIECES ? (wave * APIECES + q) * 1024 : BM * 128 + (wave * WPIECES + q - APIECES) * 1024);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (long)kt * (BK * 4)),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_p8;
+    unsigned a_off[2][2], w_off[2][2];
+    {
+        const int arow = wm * (BM / 2) + r, wrow = wn * (BN / 2) + r;
+        const int akey = (arow >> 1) & 7, wkey = (wrow >> 1) & 7;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int lo = 0; lo < 2; ++lo) {
+                const int c = (kb * 2 + h) * 2 + lo;
+                a_off[kb][lo] = lds0 + arow * 128 + ((c ^ akey) << 4);
+                w_off[kb][lo] = lds0 + BM * 128 + wrow * 128 + ((c ^ wkey) << 4);
+            }
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st < nk) {
+#pragma unroll
+            for (int q = 0; q < NDMA; ++q) issue_piece(q, st, st);
+        }
+
+    auto read_frags = [&](int buf, int kb, f16x8 (&ah)[TM], f16x8 (&al)[TM], f16x8 (&bh)[TN], f16x8 (&bl)[TN]) {
+        const unsigned sb = buf * STAGE_BYTES;
+        const unsigned ahp = a_off[kb][0] + sb, alp = a_off[kb][1] + sb, whp = w_off[kb][0] + sb, wlp = w_off[kb][1] + sb;
+        bh[0] = lds_read128<0>(whp);
+        ah[0] = lds_read128<0>(ahp);
+        bl[0] = lds_read128<0>(wlp);
+        al[0] = lds_read128<0>(alp);
+        if constexpr (TM == 2) { ah[TM - 1] = lds_read128<4096>(ahp); al[TM - 1] = lds_read128<4096>(alp); }
+        if constexpr (TN == 2) { bh[TN - 1] = lds_read128<4096>(whp); bl[TN - 1] = lds_read128<4096>(wlp); }
+    };
+    auto mfma_slot = [&](int sidx, const f16x8 (&ah)[TM], const f16x8 (&al)[TM], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
+        const int t = sidx / (TM * TN), i = (sidx / TN) % TM, j = sidx % TN;
+        if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+    };
+    auto mfmas = [&](const f16x8 (&ah)[TM], const f16x8 (&al)[TM], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
+#pragma unroll
+        for (int sidx = 0; sidx < NMF; ++sidx) mfma_slot(sidx, ah, al, bh, bl);
+    };
+
+    f16x8 ah0[TM], al0[TM], bh0[TN], bl0[TN], ah1[TM], al1[TM], bh1[TN], bl1[TN];
+    wait_vmcnt_units<NDMA>(min(STAGES - 2, nk - 1));
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, ah0, al0, bh0, bl0);
+    int kt = 0, buf = 0;
+    for (; kt + STAGES - 1 < nk; ++kt) {               // steady state (see gemm_p8_kernel)
+        const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
+        const int fbuf = (buf == 0) ? STAGES - 1 : buf - 1;
+        read_frags(buf, 1, ah1, al1, bh1, bl1);
+        wait_lgkmcnt<NRD>();
+        mfmas(ah0, al0, bh0, bl0);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt<(STAGES - 3) * NDMA>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(nbuf, 0, ah0, al0, bh0, bl0);
+        wait_lgkmcnt<NRD>();
+#pragma unroll
+        for (int sidx = 0; sidx < (NMF > NDMA ? NMF : NDMA); ++sidx) {
+            if (sidx < NMF) mfma_slot(sidx, ah1, al1, bh1, bl1);
+            if (sidx < NDMA) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece(sidx, kt + STAGES - 1, fbuf);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nbuf;
+    }
+    for (; kt < nk; ++kt) {                            // drain
+        const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
+        read_frags(buf, 1, ah1, al1, bh1, bl1);
+        wait_lgkmcnt<NRD>();
+        mfmas(ah0, al0, bh0, bl0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            wait_vmcnt_units<NDMA>(min(STAGES - 3, nk - 2 - kt));
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(nbuf, 0, ah0, al0, bh0, bl0);
+            wait_lgkmcnt<NRD>();
+        } else {
+            wait_lgkmcnt<0>();
+        }
+        mfmas(ah1, al1, bh1, bl1);
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nbuf;
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
+    if (g.splitk > 1) {
+        float* __restrict__ P = g.partial + (long)blockIdx.y * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                partial_tile32(g, P, m0 + wm * (BM / 2) + i * 32 + r, n0 + wn * (BN / 2) + j * 32, h, acc[i][j]);
+        return;
+    }
+    const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            epilogue_tile32(g, epi, m0 + wm * (BM / 2) + i * 32 + r, n0 + wn * (BN / 2) + j * 32, h, acc[i][j]);
+}
+
+template <int BM, int BN, int STAGES>
+static void launch_p8_sm_cfg(const GemmArgs& g, hipStream_t s) {
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    const size_t lds = STAGES * (BM + BN) * 128;
+    if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_sm_kernel<BM, BN, STAGES, 1>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
+    else hipLaunchKernelGGL((gemm_p8_sm_kernel<BM, BN, STAGES, 0>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
+}
+bool gemm_p8_sm_eligible(const GemmArgs& g) {
+    return g.Wp != nullptr && g.a_packed && g.amode == 0 && g.batch == 1 && g.K % 32 == 0 && (g.lda % 8) == 0;
+}
+// force_cfg 20: 64x64 x 4 stages (default), 21: 128x64 x 3 stages, 22: 128x128 x 3 stages
+void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return;
+    switch (g.force_cfg) {
+        case 21: launch_p8_sm_cfg<128, 64, 3>(g, s); break;
+        case 22: launch_p8_sm_cfg<128, 128, 3>(g, s); break;
+        default: launch_p8_sm_cfg<64, 64, 4>(g, s); break;
+    }
+}
+
 int gemm_p8_variant(const GemmArgs& g);
 void launch_gemm_p8(const GemmArgs& g_in, hipStream_t s) {
     if (g_in.M <= 0 || g_in.N <= 0) return;

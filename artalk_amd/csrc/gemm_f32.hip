@@ -207,15 +207,23 @@ void launch_gemm(const GemmArgs& g, hipStream_t s) {
 namespace artalk {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
     const long total = (long)g.M * g.N;
+    const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+    if (epi.vec && (((unsigned long long)g.partial >> 2) & 3) == 0) {   // 4 consecutive columns per thread, shared epilogue (fp32 or P8 result)
+        for (long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 4; idx < total; idx += (long)gridDim.x * 1024) {
+            const int row = (int)(idx / g.N), col0 = (int)(idx - (long)row * g.N);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int y = 0; y < g.splitk; ++y) v += *reinterpret_cast<const f32x4*>(g.partial + (long)y * total + idx);
+            epilogue_row4(g, epi, row, col0, v);
+        }
+        return;
+    }
     for (long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 4; idx < total; idx += (long)gridDim.x * 1024) {
         const int row = (int)(idx / g.N), col0 = (int)(idx - (long)row * g.N);
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        const bool vec = (g.N % 4 == 0);
-        const int nv = vec ? 4 : min(4, (int)(total - idx));
+        const int nv = min(4, (int)(total - idx));
         for (int y = 0; y < g.splitk; ++y) {
             const float* P = g.partial + (long)y * total + idx;
-            if (vec) { const f32x4 t = *reinterpret_cast<const f32x4*>(P); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
-            else for (int e = 0; e < nv; ++e) v[e] += P[e];
+            for (int e = 0; e < nv; ++e) v[e] += P[e];
         }
         for (int e = 0; e < nv; ++e) {
             int rr = row, cc = col0 + e;

@@ -112,12 +112,22 @@ def test_gemm_p8_dma_pipeline_and_producers():
     # LayerNorm -> P8 (flag in the high bits of `act`: see artalk_op_layernorm)
     assert L.artalk_op_layernorm(_p(dX), _p(Ap), _p(dlw), _p(dlb), None, None, M, K, 1e-5, 0x100, None) == 0
     out = torch.full((M, N), float("nan"), device="cuda")
-    for cfg in (2, 7, 8, 6, 0, 1):  # DMA pipeline 128x128 / 256x256 / 256x128, register-staged 128x128 and 64x64, all fed with the P8 activation
+    # LDS-DMA kernels 128x128 / 256x256 / two-workgroup / 256x128, register-staged 128x128 and 64x64, the small-grid LDS-DMA kernel
+    # (64x64, 128x64, 128x128; 20 | 3 << 8 = split-K 3), all fed with the P8 activation
+    for cfg in (2, 7, 8, 6, 0, 1, 20, 21, 22, 20 | (3 << 8), 21 | (5 << 8)):
         out.fill_(float("nan"))
         assert L.artalk_op_gemm_f16s_packed(_p(Ap), 1, K, _p(Wp), _p(db), _p(out), M, N, K, 0, cfg, None) == 0
         torch.cuda.synchronize()
         err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
         assert err < 2e-6, (cfg, err)
+    # small ragged shapes of the AR scale steps through the small-grid kernel (M = 80 / 400 rows, K = 1024 here)
+    for Ms in (80, 400):
+        for cfg in (20, 21, 20 | (4 << 8)):
+            o2 = torch.full((Ms, N), float("nan"), device="cuda")
+            assert L.artalk_op_gemm_f16s_packed(_p(Ap), 1, K, _p(Wp), _p(db), _p(o2), Ms, N, K, 0, cfg, None) == 0
+            torch.cuda.synchronize()
+            err = (o2.cpu().double() - ref[:Ms]).abs().max().item() / ref.abs().max().item()
+            assert err < 2e-6, (Ms, cfg, err)
 
 
 def test_gemm_exact_integers():

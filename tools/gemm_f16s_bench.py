@@ -8,7 +8,12 @@ L = capi.lib()
 p = lambda t: C.c_void_p(t.data_ptr())
 SHAPES = [("w2v qkv", 19200, 3072, 1024), ("w2v out", 19200, 1024, 1024), ("w2v ff1", 19200, 4096, 1024), ("w2v ff2", 19200, 1024, 4096),
           ("conv1", 614400, 512, 1536), ("ada", 5792, 56832, 1024), ("ar ffn1 p4", 3200, 3072, 768), ("ar ffn2 p4", 3200, 768, 3072),
-          ("ar qkv p2", 800, 2304, 768), ("ar ffn2 p2", 800, 768, 3072)]
+          ("ar qkv p2", 800, 2304, 768), ("ar ffn2 p2", 800, 768, 3072),
+          # per clip group of 16 (what one of the two concurrent AR graphs launches at batch 32)
+          ("g qkv p4", 1600, 2304, 768), ("g proj p4", 1600, 768, 768), ("g ffn1 p4", 1600, 3072, 768), ("g ffn2 p4", 1600, 768, 3072),
+          ("g qkv p3", 800, 2304, 768), ("g proj p3", 800, 768, 768), ("g ffn1 p3", 800, 3072, 768), ("g ffn2 p3", 800, 768, 3072),
+          ("g qkv p2", 400, 2304, 768), ("g proj p2", 400, 768, 768), ("g ffn1 p2", 400, 3072, 768), ("g ffn2 p2", 400, 768, 3072),
+          ("g qkv p1", 80, 2304, 768), ("g ffn2 p1", 80, 768, 3072), ("g hist kv", 2896, 1536, 768)]
 variants = [(0, 0), (1, 1), (2, 1), (6, 1)]   # (cfg, A packed): 0/1 register-staged 128x128 / 64x64, 2 LDS-DMA 128x128, 6 LDS-DMA 256x128   # (tile cfg, A packed): cfg 2 = LDS-DMA pipelined kernel
 only = os.environ.get("GEMM_ONLY")
 if only:
@@ -24,7 +29,7 @@ for name, M, N, K in SHAPES:
     ref = A[:256].double() @ W.double().t() + b.double()
     line = f"{name:12s} M={M:6d} N={N:5d} K={K:4d} "
     for cfg, apk in variants:
-        if cfg >= 2 and M < 3000: continue
+        if 2 <= cfg < 20 and M < 3000: continue
         best = 1e9
         n = 3 if M * N * K > 1e11 else 10
         for rnd in range(3):

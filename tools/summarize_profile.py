@@ -3,6 +3,7 @@
 
   summarize_profile.py stats  <dir> <out.csv>            kernel-trace --stats: the per-kernel table
   summarize_profile.py pmc    <fetch_dir> <write_dir> <out.json>   FETCH_SIZE / WRITE_SIZE passes -> bytes per launch
+  summarize_profile.py shapes <dir> <out.csv>            kernel-trace: time per (kernel, grid size), the launch-shape view
 
 HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
 exactly half of a wide (16 B/lane) coalesced read stream, so reads = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact.
@@ -36,6 +37,20 @@ def stats(d, out):
     print(open(out).read())
 
 
+def shapes(d, out):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(find(d, "*kernel_trace.csv"))):
+        k = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
+        agg[k][0] += 1
+        agg[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tot = sum(v[1] for v in agg.values())
+    with open(out, "w") as f:
+        f.write("kernel,blocks_x,grid_y,grid_z,calls,total_ms,avg_us,pct\n")
+        for k, v in sorted(agg.items(), key=lambda t: -t[1][1])[:60]:
+            f.write(f"\"{k[0]}\",{k[1]},{k[2]},{k[3]},{v[0]},{v[1] / 1e3:.3f},{v[1] / v[0]:.2f},{100 * v[1] / tot:.2f}\n")
+    print(open(out).read())
+
+
 def pmc(fd, wd, out):
     res = collections.defaultdict(dict)
     for tag, d in (("FETCH_SIZE", fd), ("WRITE_SIZE", wd)):
@@ -63,7 +78,9 @@ def pmc(fd, wd, out):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "shapes":
+        shapes(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
