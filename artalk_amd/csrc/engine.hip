@@ -60,7 +60,7 @@ struct Workspace {
     float *h0 = nullptr, *h1 = nullptr, *xln = nullptr, *qkv = nullptr, *att = nullptr, *ffn = nullptr;
     float* silu_cond = nullptr;     // [maxC*181, 1024]
     // AR
-    float *ada = nullptr, *style_cond = nullptr, *prev_in = nullptr, *cache = nullptr;
+    float *ada = nullptr, *style_cond = nullptr, *prev_in = nullptr, *prev_in_p8 = nullptr, *cache = nullptr;
     float *x = nullptr, *xmod = nullptr, *attn_out = nullptr, *ffn_h = nullptr, *logits = nullptr;
     float *fhat = nullptr, *nextfeat = nullptr;
     float* splitk = nullptr; int64_t splitk_floats = 0;   // partial sums of split-K GEMMs
@@ -497,21 +497,23 @@ void run_vae_stack(artalk_model* m, const VAESide& S, int B, int T, int split, h
     const artalk_config& c = m->cfg;
     Workspace& w = m->view ? *m->view : m->ws;
     const int H = c.vae_hidden, M = B * T, F = H * 3 / 2;
+    const int p8 = m->precision == 1 ? 1 : 0;      // GEMM-only activations in the P8 split format (see run_chunk_body)
+    const int AP = p8 ? LF_A_P8 : 0;
     for (int i = 0; i < c.vae_depth; ++i) {
         const VAELayer& L = S.layers[i];
-        layernorm(w.vh, w.vln, L.lnw, L.lnb, M, H, 1e-5f, ACT_NONE, s);
-        linear(m, w.vln, H, L.qkv_w, nullptr, w.vqkv, 3 * H, M, 3 * H, H, ACT_NONE, nullptr, s);
+        layernorm(w.vh, w.vln, L.lnw, L.lnb, M, H, 1e-5f, ACT_NONE, s, p8);
+        linear(m, w.vln, H, L.qkv_w, nullptr, w.vqkv, 3 * H, M, 3 * H, H, ACT_NONE, nullptr, s, AP);
         AttnArgs a;
         a.Q = w.vqkv; a.K = w.vqkv + H; a.V = w.vqkv + 2 * H; a.ldq = a.ldk = a.ldv = 3 * H;
         a.q_bstride = a.k_bstride = a.v_bstride = (long)T * 3 * H;
         a.O = w.vatt; a.ldo = H; a.o_bstride = (long)T * H;
         a.B = B; a.H = c.vae_heads; a.HD = H / c.vae_heads; a.Lq = T; a.Lk = T;
         a.scale = 1.0f / std::sqrt((float)H);      // hidden_dim**-0.5, NOT head_dim (bitwise_vae.py:198)
-        a.split_q = split; a.split_k = split;
+        a.split_q = split; a.split_k = split; a.out_p8 = p8;
         launch_attention(a, s);
-        linear(m, w.vatt, H, L.out_w, L.out_b, w.vh, H, M, H, H, ACT_NONE, w.vh, s);
-        linear(m, w.vh, H, L.m1_w, L.m1_b, w.vmlp, F, M, F, H, ACT_GELU_TANH, nullptr, s);
-        linear(m, w.vmlp, F, L.m2_w, L.m2_b, w.vh, H, M, H, F, ACT_NONE, w.vh, s);
+        linear(m, w.vatt, H, L.out_w, L.out_b, w.vh, H, M, H, H, ACT_NONE, w.vh, s, AP);
+        linear(m, w.vh, H, L.m1_w, L.m1_b, w.vmlp, F, M, F, H, ACT_GELU_TANH, nullptr, s, p8 ? LF_C_P8 : 0);   // A = residual stream (fp32)
+        linear(m, w.vmlp, F, L.m2_w, L.m2_b, w.vh, H, M, H, F, ACT_NONE, w.vh, s, AP);
     }
 }
 
@@ -539,10 +541,12 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
     // format by their producers, which lets every block GEMM use the LDS-DMA kernels (gemm_p8_sm_kernel at these grid sizes)
     const int p8 = m->precision == 1 ? 1 : 0;
     // K/V of the 181 history tokens, once per layer (raw prev tokens, not modulated: app/transformer.py:68-70)
+    if (p8) launch_pack_split(w.prev_in, reinterpret_cast<unsigned int*>(w.prev_in_p8), (long)B * kNTok * kE, false, s);   // one split for the 12 layers
     for (int l = 0; l < c.ar_depth; ++l) {
         const ARLayer& L = m->ar[l];
         GemmArgs g;
-        g.A = w.prev_in; g.lda = kE; g.W = L.qkv_w + (long)kE * kE; g.ldw = kE; g.bias = L.qkv_b + kE;
+        g.A = p8 ? w.prev_in_p8 : w.prev_in; g.a_packed = p8;
+        g.lda = kE; g.W = L.qkv_w + (long)kE * kE; g.ldw = kE; g.bias = L.qkv_b + kE;
         g.C = w.cache + l * cache_l + kE; g.ldc = 3 * kE; g.cmap = rowmap(kNTok, 2 * kNTok, 0);
         g.M = B * kNTok; g.N = 2 * kE; g.K = kE;
         gemm(m, g, s);
@@ -614,7 +618,7 @@ Workspace clip_view(const artalk_model* m, int b0, int branch) {
     const artalk_config& c = m->cfg;
     Workspace v = m->ws;
     const long b = b0;
-    v.ada += b * kNTok * m->ada_n; v.style_cond += b * kE; v.prev_in += b * kNTok * kE;
+    v.ada += b * kNTok * m->ada_n; v.style_cond += b * kE; v.prev_in += b * kNTok * kE; v.prev_in_p8 += b * kNTok * kE;
     v.cache += b * 2 * kNTok * 3 * kE;
     v.x += b * 100 * kE; v.xmod += b * 100 * kE; v.attn_out += b * 100 * kE; v.ffn_h += b * 100 * 4 * kE;
     v.logits += b * 100 * 2 * c.code_dim; v.fhat += b * 100 * c.code_dim; v.nextfeat += b * 100 * c.code_dim;
@@ -726,7 +730,7 @@ int reserve(artalk_model* m, int maxB, int maxC) {
     w.silu_cond = F((int64_t)maxC * kNTok * kCond);
     w.ada = F((int64_t)maxB * kNTok * m->ada_n);
     w.style_cond = F((int64_t)maxB * kE);
-    w.prev_in = F((int64_t)maxB * kNTok * kE);
+    w.prev_in = F((int64_t)maxB * kNTok * kE); w.prev_in_p8 = F((int64_t)maxB * kNTok * kE);
     w.cache = F((int64_t)c.ar_depth * maxB * 2 * kNTok * 3 * kE);
     w.x = F((int64_t)maxB * 100 * kE); w.xmod = F((int64_t)maxB * 100 * kE); w.attn_out = F((int64_t)maxB * 100 * kE);
     w.ffn_h = F((int64_t)maxB * 100 * 4 * kE); w.logits = F((int64_t)maxB * 100 * 2 * c.code_dim);
