@@ -12,6 +12,7 @@
 //  * the softmax statistics of a query are reduced over 4 registers and two cross-lane steps (xor 16, 32),
 //  * the S^T accumulator is directly the B operand of O^T += V^T P^T (guide section 3 "accumulator as next
 //    operand"): k-slot g of step j carries key 4g+j, and the V fragment is read with the same permutation.
+#include <cstdlib>
 #include "common.h"
 
 namespace artalk {
@@ -193,8 +194,175 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     }
 }
 
+// ---- short-query variant (AR scale steps: 1..50 queries against 182..312 keys).  In the kernel above such a launch has
+// one to four active waves per workgroup and walks the keys serially through LDS behind two barriers per 64 keys: 28 us per launch,
+// all latency.  Here ONE 16-query tile is shared by the 4 waves of a workgroup and the KEYS are split over them (16-key tiles
+// t = w, w+4, ...): K and V fragments go straight from global memory into MFMA operand registers (their lane maps are
+// row-contiguous: 64-byte pieces of a key row for K, whole 256-byte rows for V), the next tile's loads are issued before
+// the current tile's MFMAs, no LDS and no barrier in the loop; the four partial (m, l, O) are merged through LDS at the end.
+template <int HD>
+__global__ __launch_bounds__(256) void attention_short_kernel(const AttnArgs a) {
+    static_assert(HD == 64, "head dim");
+    constexpr int NC = 4, NDT = 4;
+    __shared__ __attribute__((aligned(16))) float Os[4][16][HD + 4];
+    __shared__ float Ms[4][16], Ls[4][16];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 16;
+    const int qi = q0 + r;
+    const bool qvalid = qi < a.Lq;
+
+    f32x4 qf[NC];
+    {
+        const float* qp = a.Q + (long)b * a.q_bstride + (long)qi * a.ldq + h * HD;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            qf[c] = qvalid ? *reinterpret_cast<const f32x4*>(qp + 4 * (g + 4 * c)) : z;
+        }
+        if (a.l2norm) {
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ss += qf[c][e] * qf[c][e];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float den = fmaxf(sqrtf(ss), 1e-12f);
+            const float mul = a.qscale[h];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qf[c][e] = (qf[c][e] / den) * mul;
+        }
+        if (a.scale != 1.0f) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qf[c][e] *= a.scale;
+        }
+    }
+    const float* Kb = a.K + (long)b * a.k_bstride + h * HD;
+    const float* Vb = a.V + (long)b * a.v_bstride + h * HD;
+    const int ntiles = (a.Lk + 15) >> 4;
+
+    // fragment loads of key tile t: K rows t*16 + r (chunks g + 4c), V rows t*16 + 4g + j (columns 4r..4r+3); rows >= Lk read row Lk-1
+    f32x4 kf[2][NC], vf[2][4];
+    auto load_tile = [&](int t, int slot) {
+        const int kr = min(t * 16 + r, a.Lk - 1);
+        const float* kp = Kb + (long)kr * a.ldk;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) kf[slot][c] = *reinterpret_cast<const f32x4*>(kp + 4 * (g + 4 * c));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int vr = min(t * 16 + 4 * g + j, a.Lk - 1);
+            vf[slot][j] = *reinterpret_cast<const f32x4*>(Vb + (long)vr * a.ldv + NDT * r);
+        }
+    };
+
+    float m_run = -INFINITY, l_part = 0.f;
+    f32x4 ot[NDT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; ot[d] = z; }
+
+    auto do_tile = [&](int t, int slot) {
+        if (a.l2norm) {     // key row norm: this lane holds 16 of the 64 elements, the rest sit in the lanes g' != g of the same r
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ss += kf[slot][c][e] * kf[slot][c][e];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);     // one division per key row; x * (1/n) instead of x / n: 1 ulp
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kf[slot][c] *= inv;
+        }
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};          // st[j] = S[key t*16 + 4g + j][query qi]
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[slot][c][e], qf[c][e], st, 0, 0, 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sv = (t * 16 + 4 * g + j < a.Lk) ? st[j] : -INFINITY;
+            st[j] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = expf(m_run - m_safe);
+        m_run = m_new;
+        float ps = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float p = expf(st[j] - m_safe); st[j] = p; ps += p; }
+        l_part = l_part * alpha + ps;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) ot[d] *= alpha;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int d = 0; d < NDT; ++d) ot[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[slot][j][d], st[j], ot[d], 0, 0, 0);
+    };
+
+    int t = wave;
+    if (t < ntiles) load_tile(t, 0);
+    while (t < ntiles) {            // unrolled by two so that the fragment slots are compile-time register sets
+        if (t + 4 < ntiles) load_tile(t + 4, 1);
+        do_tile(t, 0);
+        t += 4;
+        if (t >= ntiles) break;
+        if (t + 4 < ntiles) load_tile(t + 4, 0);
+        do_tile(t, 1);
+        t += 4;
+    }
+    float l = l_part;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    // ---- merge the four waves' partial results: ot[dd][reg] = O[query r][d = NDT*(4g+reg) + dd] ----
+    if (g == 0) { Ms[wave][r] = m_run; Ls[wave][r] = l; }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const f32x4 o = {ot[0][reg], ot[1][reg], ot[2][reg], ot[3][reg]};
+        *reinterpret_cast<f32x4*>(&Os[wave][r][NDT * (4 * g + reg)]) = o;
+    }
+    __syncthreads();
+    {
+        const int q = tid & 15, dc = tid >> 4;        // query, 4-float chunk of d
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, Ms[w][q]);
+        float L = 0.f;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = Ms[w][q];
+            const float sc = (mw == -INFINITY) ? 0.f : expf(mw - M);
+            L += Ls[w][q] * sc;
+            const f32x4 ow = *reinterpret_cast<const f32x4*>(&Os[w][q][4 * dc]);
+            o += ow * sc;
+        }
+        if (q0 + q < a.Lq) {
+            const float inv = 1.0f / L;
+            float* op = a.O + (long)b * a.o_bstride + (long)(q0 + q) * a.ldo + h * HD;
+            if (a.out_p8) store_p8x4(op, 4 * dc, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+            else { const f32x4 v = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv}; *reinterpret_cast<f32x4*>(op + 4 * dc) = v; }
+        }
+    }
+}
+
 void launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.Lq <= 0) return;
+    static const int short_lq = getenv("ARTALK_ATTN_SHORT_LQ") ? atoi(getenv("ARTALK_ATTN_SHORT_LQ")) : 64;   // tuning
+    if (a.HD == 64 && a.split_q == 0 && a.Lq <= short_lq && a.Lk >= 64) {
+        hipLaunchKernelGGL(attention_short_kernel<64>, dim3((a.Lq + 15) / 16, a.H, a.B), dim3(256), 0, s, a);
+        return;
+    }
     dim3 grid((a.Lq + 63) / 64, a.H, a.B), block(256);
     if (a.HD == 64)
         hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, a);

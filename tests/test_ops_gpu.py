@@ -171,7 +171,10 @@ def test_layernorm(D, affine, mod, act, eps):
 @pytest.mark.parametrize("B,H,HD,Lq,Lk,l2norm,split", [
     (3, 16, 64, 199, 199, 0, 0),      # wav2vec2 encoder
     (2, 12, 64, 25, 212, 1, 0),       # AR step 2 with KV cache: 181 history + 6 + 25 keys
-    (2, 12, 64, 1, 182, 1, 0),        # AR step 0
+    (2, 12, 64, 1, 182, 1, 0),        # AR step 0 (short-query kernel: keys split over the waves)
+    (2, 12, 64, 5, 187, 1, 0),        # AR step 1
+    (2, 12, 64, 50, 262, 1, 0),       # AR step 3 (four query tiles)
+    (2, 8, 64, 16, 70, 0, 0),         # short-query kernel without L2 norm, ragged last key tile
     (2, 12, 64, 100, 362, 1, 0),      # AR step 4
     (2, 8, 64, 200, 200, 0, 100),     # VAE decoder mask
     (2, 8, 64, 100, 100, 0, 0),       # VAE encoder
