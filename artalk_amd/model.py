@@ -61,6 +61,7 @@ class BitwiseARModel:
         self._reserved = (0, 0)
         self.check_finite = True   # f16x3 mode: verify the result is finite (one small reduction + sync per call)
         self._precision = "f16x3"   # default GEMM arithmetic (set_precision); applied when the weights are loaded
+        self._overlap = False       # overlapped wav2vec2 / AR schedule (set_overlap), opt-in
         self._stream = None      # dedicated HIP stream (hipGraph capture is not allowed on the legacy default stream)
         self.last_aux = {}
 
@@ -133,6 +134,8 @@ class BitwiseARModel:
         if errors:
             raise RuntimeError("Error(s) in loading state_dict for BitwiseARModel:\n\t" + "\n\t".join(errors[:12]))
         self._loaded = True
+        if self._overlap:
+            capi.lib().artalk_set_overlap(self._h, 1)
         self.set_precision(self._precision)
         return self
 
@@ -176,6 +179,12 @@ class BitwiseARModel:
         """hipGraph replay of the AR/VAE body; ``branches`` (0 auto, 1, 2, 4) = concurrent clip groups; the split-K thresholds are
         tuning knobs (multiples of 16, 0 = keep)."""
         capi.lib().artalk_set_graphs(self._h, int(bool(on)) | (int(branches) << 8) | ((splitk_tiles // 16) << 16) | ((splitk_target // 16) << 24))
+
+    def set_overlap(self, on: bool = True):
+        """Overlapped schedule (default off): wav2vec2 of chunk index j+1 beside the AR/VAE body of chunk index j."""
+        self._overlap = bool(on)
+        if self._h is not None:
+            capi.lib().artalk_set_overlap(self._h, int(self._overlap))
 
     def get_profile(self):
         out = (C.c_double * 10)()

@@ -73,6 +73,7 @@ def main():
                     help="GEMM arithmetic: exact fp32 MFMA, or fp16 operand-split MFMA with fp32-class accuracy")
     ap.add_argument("--branches", type=int, default=0, help="concurrent clip groups of the AR body (0 = auto)")
     ap.add_argument("--splitk", default="0,0", help="tuning: split-K tile threshold,target workgroups (0 = keep)")
+    ap.add_argument("--overlap", action="store_true", help="overlapped schedule: wav2vec2 of chunk index j+1 beside the AR/VAE body of j")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra (untimed) f32-mode measurement")
     ap.add_argument("--cpu-clips", type=int, default=12)
@@ -118,6 +119,8 @@ def main():
     frames_per_clip = model.seq_length(audios[0].shape[0])
     chunks = sum(model.n_chunks(a.shape[0]) for a in audios)
     model.reserve(B, chunks)
+    if args.overlap:
+        model.set_overlap(True)
     gathered = torch.empty(world * B, frames_per_clip, cfg.motion_dim, device=dev) if world > 1 else None
 
     def step():
@@ -189,6 +192,9 @@ def main():
                    "model_config": args.config},
         "fps_per_clip": round(value / (B * world), 1),
         "algorithmic_tflops": round(value * GFLOP_PER_FRAME / 1e3, 2),
+        # overlapped schedule: the wav2vec2 buckets are measured on their own stream and run BESIDE ada/ar of the previous chunk
+        # index, so the buckets add up to more than total_ms; ada_ms includes waiting for the features of its chunk index
+        "schedule": "overlapped (wav2vec2 of chunk index j+1 beside the AR/VAE body of j)" if (args.overlap and B >= 8) else "sequential",
         "stages_ms": {k: round(prof[k], 2) for k in ("style_ms", "w2v_conv_ms", "w2v_encoder_ms", "ada_ms", "ar_ms", "vae_ms", "total_ms")},
         "roofline": roofline,
         "parity": parity,

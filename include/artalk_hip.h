@@ -133,6 +133,10 @@ int artalk_set_precision(artalk_model* m, int mode);
  * Bits 16-23 / 24-31, when non-zero, override the split-K policy in units of 16 tiles (split when a GEMM has fewer output
  * tiles than the first, aim for the second; defaults 192 / 384 measured best). */
 int artalk_set_graphs(artalk_model* m, int enable);
+/* Overlapped schedule of artalk_infer (default 0 = off; when on, used from 8 clips up): wav2vec2 runs chunk index by chunk
+ * index on a low-priority stream of the library while the latency-bound AR/VAE body of the previous chunk index runs on the
+ * caller's stream.  Measured +3.5 % at batch 32 (both sides slow each other down); 0 = all of wav2vec2 first. */
+int artalk_set_overlap(artalk_model* m, int enable);
 
 /* ---- single-kernel entry points for the parity tests (device pointers, row-major f32) ---- */
 /* C[M,N] = R + gate * act(A[M,K] W[N,K]^T + bias); act: 0 none, 1 gelu(erf), 2 gelu(tanh), 3 leaky_relu(0.2). K % 32 == 0 */
