@@ -356,6 +356,209 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const AttnArgs a) 
     }
 }
 
+// ---- f16x3 mode: the same attention on the fp16 matrix cores with every operand split hi + lo (the arithmetic of gemm_f16s.hip,
+// unscaled: |q|, |k|, |v| are O(1..10), p <= 1).  v_mfma_f32_16x16x32_f16, three products per fp32 product:
+//   S^T tile (16 keys x 16 queries) = 2 k-blocks x {Kh Qh, Kl Qh, Kh Ql}                       6 MFMAs of 16 cycles (fp32: 16 of 32)
+//   O^T (16 d x 16 queries) += V^T P^T over 32 keys = {Vh Ph, Vl Ph, Vh Pl}                     3 MFMAs per d tile
+// K and V are staged into LDS already split (row-major fp16 hi / lo images, 160-byte rows: conflict-free for both read kinds).
+// The V^T operand needs 8 consecutive KEYS per lane at one d: read by ds_read_b64_tr_b16 (4 keys x 16 d block per 16 lanes,
+// delivered column-major), two reads per operand.  The k slots of the PV MFMA are assigned so that the S^T accumulator is the
+// P^T operand without any data movement: slot (g, e) = key 32T + 4g + e for e < 4 (tile 2T), key 32T + 16 + 4g + (e - 4) (tile 2T+1).
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ void split4(const f32x4 x, f16x4_t& hi, f16x4_t& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const _Float16 a = (_Float16)x[e]; hi[e] = a; lo[e] = (_Float16)(x[e] - (float)a); }
+}
+__global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs a) {
+    constexpr int HD = 64, KB = 64, PB = 160;      // keys per block, bytes per LDS row (64 halves + pad)
+    __shared__ __attribute__((aligned(16))) unsigned char Kh[KB * PB], Kl[KB * PB], Vh[KB * PB], Vl[KB * PB];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int qblk0 = blockIdx.x * 64;
+    const int q0 = qblk0 + wave * 16;
+    const int qi = q0 + r;
+    const bool qvalid = qi < a.Lq;
+    const bool wave_active = q0 < a.Lq;
+
+    // ---- Q fragments (B operand of S^T): lane (r, g) holds Q[qi][8g + 32kb .. +7], split ----
+    h8_t qh[2], ql[2];
+    {
+        const float* qp = a.Q + (long)b * a.q_bstride + (long)qi * a.ldq + h * HD;
+        f32x4 x[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                x[kb][u] = qvalid ? *reinterpret_cast<const f32x4*>(qp + 8 * g + 32 * kb + 4 * u) : z;
+            }
+        if (a.l2norm) {
+            float ss = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ss += x[kb][u][e] * x[kb][u][e];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float den = fmaxf(sqrtf(ss), 1e-12f);
+            const float mul = a.qscale[h];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[kb][u][e] = (x[kb][u][e] / den) * mul;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f16x4_t h0, l0, h1, l1;
+            split4(x[kb][0] * a.scale, h0, l0);
+            split4(x[kb][1] * a.scale, h1, l1);
+            qh[kb] = h8_t{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            ql[kb] = h8_t{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        }
+    }
+    const int klim = (a.split_q > 0 && qi < a.split_q) ? a.split_k : a.Lk;
+    const int qblk_last = min(qblk0 + 63, a.Lq - 1);
+    const int lk_wg = (a.split_q > 0 && qblk_last < a.split_q) ? a.split_k : a.Lk;
+
+    float m_run = -INFINITY, l_part = 0.f;
+    f32x4 ot[4];       // ot[dt][reg] = O[query r][d = 16 dt + 4 g + reg] (unnormalised)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; ot[d] = z; }
+
+    const float* Kb = a.K + (long)b * a.k_bstride + h * HD;
+    const float* Vb = a.V + (long)b * a.v_bstride + h * HD;
+    // transposed-read lane role inside its group of 16: lane 4q + p supplies row q, columns 4p .. 4p+3
+    const int trq = r >> 2, trp = r & 3;
+
+    for (int kb0 = 0; kb0 < lk_wg; kb0 += KB) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KB * 16 / 256; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx >> 4, c4 = (idx & 15) * 4;
+            const int kr = kb0 + row;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (kr < a.Lk) {
+                kv = *reinterpret_cast<const f32x4*>(Kb + (long)kr * a.ldk + c4);
+                vv = *reinterpret_cast<const f32x4*>(Vb + (long)kr * a.ldv + c4);
+            }
+            if (a.l2norm) {
+                float ss = kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2] + kv[3] * kv[3];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                const float den = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kv[e] = kv[e] / den;
+            }
+            f16x4_t hh, ll;
+            split4(kv, hh, ll);
+            *reinterpret_cast<f16x4_t*>(Kh + row * PB + c4 * 2) = hh;
+            *reinterpret_cast<f16x4_t*>(Kl + row * PB + c4 * 2) = ll;
+            split4(vv, hh, ll);
+            *reinterpret_cast<f16x4_t*>(Vh + row * PB + c4 * 2) = hh;
+            *reinterpret_cast<f16x4_t*>(Vl + row * PB + c4 * 2) = ll;
+        }
+        __syncthreads();
+        if (!wave_active) continue;      // wave-uniform: EXEC stays all ones for the transposed reads below
+
+        const int ntile = min(4, (a.Lk - kb0 + 15) >> 4);
+        f32x4 st[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (t < ntile) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const int off = (t * 16 + r) * PB + (8 * g + 32 * kb) * 2;
+                    const h8_t kh = *reinterpret_cast<const h8_t*>(Kh + off), kl = *reinterpret_cast<const h8_t*>(Kl + off);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[kb], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[kb], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[kb], acc, 0, 0, 0);
+                }
+            }
+            st[t] = acc;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kidx = kb0 + t * 16 + 4 * g + j;
+                const float sv = (kidx < klim) ? st[t][j] : -INFINITY;
+                st[t][j] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = expf(m_run - m_safe);
+        m_run = m_new;
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float p = expf(st[t][j] - m_safe);
+                st[t][j] = p;
+                ps += p;
+            }
+        l_part = l_part * alpha + ps;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) ot[d] *= alpha;
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            if (2 * T < ntile) {        // tile 2T+1 may be past Lk: its p are exp(-inf) = 0 and its V rows were staged as zeros
+                f16x4_t h0, l0, h1, l1;
+                split4(st[2 * T], h0, l0);
+                split4(st[2 * T + 1], h1, l1);
+                const h8_t ph = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                const h8_t pl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                const int row1 = T * 32 + 4 * g + trq, row2 = row1 + 16;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int col = (16 * dt + 4 * trp) * 2;
+                    const f16x4_t a1 = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                        (__attribute__((address_space(3))) fp16x4_raw*)(Vh + row1 * PB + col)));
+                    const f16x4_t a2 = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                        (__attribute__((address_space(3))) fp16x4_raw*)(Vh + row2 * PB + col)));
+                    const f16x4_t b1 = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                        (__attribute__((address_space(3))) fp16x4_raw*)(Vl + row1 * PB + col)));
+                    const f16x4_t b2 = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                        (__attribute__((address_space(3))) fp16x4_raw*)(Vl + row2 * PB + col)));
+                    const h8_t vh = {a1[0], a1[1], a1[2], a1[3], a2[0], a2[1], a2[2], a2[3]};
+                    const h8_t vl = {b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3]};
+                    ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, ot[dt], 0, 0, 0);
+                    ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, ot[dt], 0, 0, 0);
+                    ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, ot[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!wave_active) return;
+    float l = l_part;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qvalid) {
+        const float inv = 1.0f / l;
+        float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            const float o0 = ot[dt][0] * inv, o1 = ot[dt][1] * inv, o2 = ot[dt][2] * inv, o3 = ot[dt][3] * inv;
+            if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3);
+            else { const f32x4 o = {o0, o1, o2, o3}; *reinterpret_cast<f32x4*>(op + d0) = o; }
+        }
+    }
+}
+
 void launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.Lq <= 0) return;
     static const int short_lq = getenv("ARTALK_ATTN_SHORT_LQ") ? atoi(getenv("ARTALK_ATTN_SHORT_LQ")) : 64;   // tuning
@@ -364,7 +567,9 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         return;
     }
     dim3 grid((a.Lq + 63) / 64, a.H, a.B), block(256);
-    if (a.HD == 64)
+    if (a.HD == 64 && a.split16)
+        hipLaunchKernelGGL(attention_f16_kernel, grid, block, 0, s, a);
+    else if (a.HD == 64)
         hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, a);
     else if (a.HD == 32)
         hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, a);

@@ -456,7 +456,7 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
         a.ldq = a.ldk = a.ldv = 3 * Hs; a.q_bstride = a.k_bstride = a.v_bstride = (long)m->Ts * 3 * Hs;
         a.O = w.att; a.ldo = Hs; a.o_bstride = (long)m->Ts * Hs;
         a.B = n; a.H = nh; a.HD = hd; a.Lq = m->Tw; a.Lk = m->Tw; a.scale = 1.0f / std::sqrt((float)hd);
-        a.out_p8 = p8;
+        a.out_p8 = p8; a.split16 = p8;
         launch_attention(a, s);
         linear(m, w.att, Hs, L.out_w, L.out_b, h, Hs, M, Hs, Hs, ACT_NONE, h, s, AP);
         layernorm(h, w.xln, L.ln2w, L.ln2b, M, Hs, c.w2v_ln_eps, ACT_NONE, s, p8);
@@ -516,7 +516,7 @@ void run_vae_stack(artalk_model* m, const VAESide& S, int B, int T, int split, h
         a.O = w.vatt; a.ldo = H; a.o_bstride = (long)T * H;
         a.B = B; a.H = c.vae_heads; a.HD = H / c.vae_heads; a.Lq = T; a.Lk = T;
         a.scale = 1.0f / std::sqrt((float)H);      // hidden_dim**-0.5, NOT head_dim (bitwise_vae.py:198)
-        a.split_q = split; a.split_k = split; a.out_p8 = p8;
+        a.split_q = split; a.split_k = split; a.out_p8 = p8; a.split16 = p8;
         launch_attention(a, s);
         linear(m, w.vatt, H, L.out_w, L.out_b, w.vh, H, M, H, H, ACT_NONE, w.vh, s, AP);
         linear(m, w.vh, H, L.m1_w, L.m1_b, w.vmlp, F, M, F, H, ACT_GELU_TANH, nullptr, s, p8 ? LF_C_P8 : 0);   // A = residual stream (fp32)
@@ -579,7 +579,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
             a.ldq = a.ldk = a.ldv = 3 * kE; a.q_bstride = a.k_bstride = a.v_bstride = (long)2 * kNTok * 3 * kE;
             a.O = w.attn_out; a.ldo = kE; a.o_bstride = (long)pn * kE;
             a.B = B; a.H = c.ar_heads; a.HD = kE / c.ar_heads; a.Lq = pn; a.Lk = kNTok + off + pn; a.scale = 1.0f;
-            a.l2norm = 1; a.qscale = L.qscale; a.out_p8 = p8;
+            a.l2norm = 1; a.qscale = L.qscale; a.out_p8 = p8; a.split16 = p8;
             launch_attention(a, s);
             GemmArgs pj;
             pj.A = w.attn_out; pj.lda = kE; pj.W = L.proj_w; pj.ldw = kE; pj.bias = L.proj_b; pj.C = w.x; pj.ldc = kE;
@@ -1302,8 +1302,10 @@ int artalk_op_layernorm(const float* X, float* Y, const float* w, const float* b
 
 int artalk_op_attention(const float* Q, const float* K, const float* V, float* O, int B, int H, int HD, int Lq, int Lk, float scale,
                         int l2norm, const float* qscale, int split, void* stream) {
-    if (!Q || !K || !V || !O || (HD != 64 && HD != 32) || (l2norm && !qscale)) return ARTALK_EINVAL;
+    if (!Q || !K || !V || !O || (HD != 64 && HD != 32) || ((l2norm & 1) && !qscale)) return ARTALK_EINVAL;
     AttnArgs a;
+    a.split16 = (l2norm >> 1) & 1;      // l2norm | 2: the fp16 operand-split kernel of f16x3 mode
+    l2norm &= 1;
     const long D = (long)H * HD;
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = a.ldk = a.ldv = a.ldo = D;
     a.q_bstride = a.o_bstride = (long)Lq * D; a.k_bstride = a.v_bstride = (long)Lk * D;

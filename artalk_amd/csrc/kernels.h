@@ -90,6 +90,7 @@ struct AttnArgs {
     int l2norm = 0; const float* qscale = nullptr;   // AR: q,k L2-normalised, q *= qscale[h]
     int split_q = 0, split_k = 0;                    // queries < split_q see keys < split_k only (VAE mask)
     int out_p8 = 0;                                  // 1: write O in the P8 split format
+    int split16 = 0;                                 // 1: fp16 operand-split MFMAs (f16x3 mode), 0: exact fp32 MFMAs
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 

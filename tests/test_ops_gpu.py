@@ -208,6 +208,13 @@ def test_attention(B, H, HD, Lq, Lk, l2norm, split):
     torch.cuda.synchronize()
     err = (out.cpu() - ref).abs().max().item()
     assert err < 2e-5, err
+    if HD == 64:     # the fp16 operand-split kernel of f16x3 mode (long-query shapes; short ones take the key-split fp32 kernel)
+        out.fill_(float("nan"))
+        assert L.artalk_op_attention(_p(dQ), _p(dK), _p(dV), _p(out), B, H, HD, Lq, Lk, scale, l2norm | 2, _p(dqs), split, None) == 0
+        torch.cuda.synchronize()
+        err16 = (out.cpu() - ref).abs().max().item()
+        print(f"attention fp32-mfma err {err:.2e}  f16-split err {err16:.2e}")
+        assert err16 < 2e-5, err16
 
 
 def test_w2v_front():

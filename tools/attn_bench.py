@@ -13,14 +13,17 @@ for name, B, H, HD, Lq, Lk, l2, split in [("w2v", 96, 16, 64, 199, 199, 0, 0), (
     D = H * HD
     Q = torch.randn(B, Lq, D, device="cuda"); K = torch.randn(B, Lk, D, device="cuda"); V = torch.randn(B, Lk, D, device="cuda")
     O = torch.empty(B, Lq, D, device="cuda"); qs = torch.ones(H, device="cuda")
-    best = 1e9
-    for _ in range(3):
-        L.artalk_op_attention(p(Q), p(K), p(V), p(O), B, H, HD, Lq, Lk, 0.125, l2, p(qs), split, s)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            L.artalk_op_attention(p(Q), p(K), p(V), p(O), B, H, HD, Lq, Lk, 0.125, l2, p(qs), split, s)
-        e1.record(); torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / 10)
     fl = 4.0 * B * H * Lq * Lk * HD
-    print(f"{name:8s} B={B} H={H} Lq={Lq} Lk={Lk}: {best*1e3:7.1f} us  {fl/best/1e9:6.1f} TF", flush=True)
+    line = f"{name:8s} B={B} H={H} Lq={Lq} Lk={Lk}:"
+    for mode, tag in ((l2, "fp32 mfma"), (l2 | 2, "f16 split")):
+        best = 1e9
+        for _ in range(3):
+            L.artalk_op_attention(p(Q), p(K), p(V), p(O), B, H, HD, Lq, Lk, 0.125, mode, p(qs), split, s)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                L.artalk_op_attention(p(Q), p(K), p(V), p(O), B, H, HD, Lq, Lk, 0.125, mode, p(qs), split, s)
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 10)
+        line += f"  {tag} {best*1e3:7.1f} us {fl/best/1e9:6.1f} TF"
+    print(line, flush=True)
