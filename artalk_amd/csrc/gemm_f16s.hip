@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        constexpr int GM = 4;
+        const int GM = g.dma_split ? 8 : 4;      // tuning: row tiles per tile group of an XCD
         const int width = GM * tiles_n;
         const int group = idx / width, first_m = group * GM;
         const int gsz = min(tiles_m - first_m, GM);
