@@ -363,10 +363,18 @@ void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
     }
     // split-K for grids that would leave most CUs idle (small-M scale steps): S workgroups per output tile
     const Workspace& cw = m->view ? *m->view : m->ws;
+    const bool sm_path = split && g.a_packed && gemm_p8_sm_eligible(g) && !gemm_p8_eligible(g);
     if (g.batch == 1 && g.amode == 0 && cw.splitk && g.K >= 256) {
         const int tiles = gemm_tile_count(g, split);
         const int lim = m->splitk_tiles, tgt = m->splitk_target;
-        if (tiles < lim) {
+        if (sm_path) {
+            // gemm_p8_sm_kernel keeps 3 K tiles in flight, so a K = 768 tile takes ~9 us and splitting it only adds the reduce pass
+            // (proj at M = 800: 9.4 us unsplit, 13.1 split in 2); K = 3072 still gains below ~192 tiles (16.0 vs 26.5 us at M = 400)
+            // (profiles/r01_gemm_f16s_bench.log)
+            int S = (g.K >= 2048 && tiles < 192) ? (tiles < 48 ? 6 : 3) : 1;
+            while (S > 1 && (int64_t)S * g.M * g.N > cw.splitk_floats) --S;
+            if (S > 1) { g.splitk = S; g.partial = cw.splitk; }
+        } else if (tiles < lim) {
             int S = std::min(std::min(g.K / 64, (tgt + tiles - 1) / tiles), 16);
             while (S > 1 && (int64_t)S * g.M * g.N > cw.splitk_floats) --S;
             if (S > 1) { g.splitk = S; g.partial = cw.splitk; }
@@ -1267,20 +1275,24 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
         if (!a_packed) return ARTALK_EINVAL;
         g.force_cfg = force_cfg == 9 ? -1 : force_cfg;   // 9: the engine's own choice between the production kernels (7 / 8)
         if (force_cfg >= 16 && force_cfg <= 18) { g.partial = (float*)bias; g.bias = nullptr; }   // timing build: `bias` carries the stamp buffer (8 x u64 per tile)
-        if ((force_cfg & 0xff) >= 20) {     // 20-22: small-grid LDS-DMA kernel; bits 8-15: split-K factor (slabs in a temporary)
+        if ((force_cfg & 0xff) >= 20 || ((force_cfg & 0xff) == 8 && (force_cfg >> 8))) {     // 20-22: small-grid LDS-DMA kernel, 8: two-workgroup kernel; bits 8-15: split-K factor (slabs in a temporary)
             g.force_cfg = force_cfg & 0xff;
             const int S = (force_cfg >> 8) & 0xff;
-            float* part = nullptr;
+            static float* part = nullptr;       // tuning/test scratch, grown on demand and kept (never used by the model path)
+            static size_t part_cap = 0;
             if (S > 1) {
-                if (hipMalloc(&part, (size_t)S * M * N * 4) != hipSuccess) return ARTALK_EHIP;
+                const size_t need = (size_t)S * M * N * 4;
+                if (need > part_cap) {
+                    (void)hipDeviceSynchronize();
+                    if (part) (void)hipFree(part);
+                    part = nullptr; part_cap = 0;
+                    if (hipMalloc(&part, need) != hipSuccess) return ARTALK_EHIP;
+                    part_cap = need;
+                }
                 g.splitk = S; g.partial = part;
             }
-            launch_gemm_p8_sm(g, (hipStream_t)stream);
-            if (S > 1) {
-                launch_splitk_reduce(g, (hipStream_t)stream);
-                (void)hipStreamSynchronize((hipStream_t)stream);
-                (void)hipFree(part);
-            }
+            if (g.force_cfg == 8) launch_gemm_p8(g, (hipStream_t)stream); else launch_gemm_p8_sm(g, (hipStream_t)stream);
+            if (S > 1) launch_splitk_reduce(g, (hipStream_t)stream);
         } else {
             launch_gemm_p8(g, (hipStream_t)stream);
         }

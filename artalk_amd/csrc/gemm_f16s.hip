@@ -676,7 +676,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
 // them), in its prologue, at its barrier or waiting for a DMA stage, the other one owns the matrix cores.  Same two-stage
 // K-step structure as the 256x256 kernel: vmcnt(0) + one barrier at the top of a step, the 8 DMA pieces of the next stage
 // issued in the MFMA gaps of this one, fragments rolling through registers behind counted lgkmcnt waits.
-template <int ABL = 0>
+template <int ABL = 0, int TAG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
     constexpr int BM = 128, BN = 128, BK = 32;
     constexpr int STAGE_BYTES = (BM + BN) * 128;     // 32 KiB
@@ -710,6 +710,9 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
     }
     const int m0 = tm * BM, n0 = tn * BN;
 
+    const int nk_all = g.K / BK;   // split-K (small grids): this workgroup owns K tiles [kt0, kt0 + nk)
+    const int kt0 = (int)((long)nk_all * blockIdx.y / g.splitk);
+    const int nk = (int)((long)nk_all * (blockIdx.y + 1) / g.splitk) - kt0;
     // ---- DMA addressing: piece = 8 rows x 128 B; wave w owns A rows 32w..32w+31 and W rows 32w..32w+31 of the tile ----
     const int prow = lane >> 3, pchunk = lane & 7;
     const unsigned char* src[NDMA];
@@ -719,8 +722,8 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
         const int gm = min(m0 + ra, g.M - 1);          // clamp: rows >= M are never stored
         const int gn = min(n0 + ra, g.N - 1);
         const int sw = (pchunk ^ ((ra >> 1) & 7)) << 4;
-        src[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda) * 4 + sw;
-        src[4 + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw) * 4 + sw;
+        src[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda + (long)kt0 * BK) * 4 + sw;
+        src[4 + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw + (long)kt0 * BK) * 4 + sw;
     }
     auto issue_piece = [&](int q, int kt, int buf) {
         unsigned char* dst = smem_p8 + buf * STAGE_BYTES + (q < 4 ? 0 : BM * 128) + (wave * 4 + (q & 3)) * 1024;
@@ -753,7 +756,6 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = g.K / BK;
 #pragma unroll
     for (int q = 0; q < NDMA; ++q) issue_piece(q, 0, 0);
 
@@ -814,11 +816,13 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
     if constexpr (ABL == 6) { if (tid == 0) stamps[2] = wall_clock64(); }
 
     const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+    float* __restrict__ P = g.splitk > 1 ? g.partial + (long)blockIdx.y * g.M * g.N : nullptr;
     auto epi_tile = [&](auto i_tag, auto j_tag) {
         constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
-        epilogue_tile32(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);
+        if (P) partial_tile32(g, P, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);     // raw sums: splitk_reduce_kernel finishes
+        else epilogue_tile32(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);
     };
     {
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -1057,7 +1061,10 @@ void launch_gemm_p8(const GemmArgs& g_in, hipStream_t s) {
         case 7: hipLaunchKernelGGL((gemm_p8_256_kernel<0>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
         case 17: hipLaunchKernelGGL((gemm_p8_256_kernel<6>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
         case 18: hipLaunchKernelGGL((gemm_p8_2wg_kernel<6>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;
-        default: hipLaunchKernelGGL((gemm_p8_2wg_kernel<0>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;
+        default:
+            if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wg_kernel<0, 1>), dim3(t128, g.splitk), dim3(256), 2 * 256 * 128, s, g);
+            else hipLaunchKernelGGL((gemm_p8_2wg_kernel<0, 0>), dim3(t128, g.splitk), dim3(256), 2 * 256 * 128, s, g);
+            break;
     }
 }
 // 0: two-workgroup 128x128 kernel (default), 1: 256x256 kernel.  The big tile halves the operand bytes per flop but its 256 KiB
