@@ -61,6 +61,23 @@ __device__ __forceinline__ void store_p8x4(float* row, int c, float x0, float x1
     *reinterpret_cast<f16x4_t*>(g + 16) = l;
 }
 
+// The same for lanes that own ADJACENT runs of 4 columns (lane L: c, lane L+1: c+4 of one 8-group, L even; all 64 lanes active):
+// neighbours trade halves so that each issues ONE 16-byte store (even lane the hi chunk, odd lane the lo chunk) instead of two 8-byte ones.
+__device__ __forceinline__ void store_p8x4_pair(float* row, int c, float x0, float x1, float x2, float x3) {
+    const float x[4] = {x0, x1, x2, x3};
+    f16x4_t h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f16(x[e] * kActScale, a, b); h[e] = a; l[e] = b; }
+    const uint2 hu = __builtin_bit_cast(uint2, h), lu = __builtin_bit_cast(uint2, l);
+    const bool odd = (c & 4) != 0;
+    const unsigned sx = odd ? hu.x : lu.x, sy = odd ? hu.y : lu.y;
+    const unsigned rx = __builtin_amdgcn_mov_dpp(sx, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    const unsigned ry = __builtin_amdgcn_mov_dpp(sy, 0xB1, 0xF, 0xF, true);
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 w = odd ? u4{rx, ry, lu.x, lu.y} : u4{hu.x, hu.y, rx, ry};
+    *reinterpret_cast<u4*>(reinterpret_cast<unsigned char*>(row) + (c >> 3) * 32 + (odd ? 16 : 0)) = w;
+}
+
 // ---- GEMM epilogue for one 32x32 MFMA tile computed with the WEIGHT rows as the A operand and the activation rows as the B
 // operand, so that the accumulator is C^T: lane (r = lane & 31, h = lane >> 5) holds
 //     v[e] = C[row][col0 + (e & 3) + 8 * (e >> 2) + 4 * h],   row = (tile's first row) + r,
