@@ -1,3 +1,5 @@
+# Collects everything kept under profiles/ for a round: run on the GPU box as
+#   gpurun -- 'bash tools/collect_profiles.sh'   (outputs under gpurun_out/r01/, then copied into profiles/ by hand)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r01
