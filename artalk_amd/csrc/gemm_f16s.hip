@@ -493,14 +493,6 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
         }
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    // Start stagger: all CUs of an XCD would otherwise reach their epilogues together and the 8 MiB burst (32 x 256 KiB) drains at
-    // the XCD's ~250 GB/s write link (33 us per tile measured); spreading the first round's start times inside each XCD lets the
-    // 4 MiB L2 absorb the stores of the few CUs that are in their epilogue at any one time.
-    if (g.stagger_ticks > 0 && blockIdx.x < 256) {
-        const unsigned long long t0 = wall_clock64();
-        const unsigned long long d = (unsigned long long)((blockIdx.x >> 3) & 31) * g.stagger_ticks / 32;
-        while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(16);
-    }
     const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
     int tm, tn;
     {
@@ -581,7 +573,6 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
     };
     // one K step from ring buffer `buf`; ISSUE: fetch stage kt+1 into the other buffer meanwhile.  The eight (k block, m tile)
     // sub-steps are spelled out with compile-time indices (fragment slots and DMA pieces are register arrays).
-    const int dma_kb = g.dma_split ? wm : 0;       // tuning: the two waves of a SIMD (w, w+4) issue their DMA in different halves of the step
     auto substep = [&](int kt, int buf, unsigned sb, auto issue_tag, auto kb_tag, auto i_tag) {
         constexpr bool ISSUE = decltype(issue_tag)::value;
         constexpr int kb = decltype(kb_tag)::value, i = decltype(i_tag)::value;
@@ -598,7 +589,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
                 else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kb][j], ah[sl], acc[i][j], 0, 0, 0);
                 else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], al[sl], acc[i][j], 0, 0, 0);
                 const int piece = i * 3 + t;     // one DMA piece per two MFMAs over the first 16 MFMAs of the step
-                if (ISSUE && kb == dma_kb && j == 1 && piece < NDMA) {
+                if (ISSUE && kb == 0 && j == 1 && piece < NDMA) {
                     __builtin_amdgcn_sched_barrier(0);
                     issue_piece(piece, kt + 1, buf ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
@@ -700,7 +691,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        const int GM = g.dma_split ? 8 : 4;      // tuning: row tiles per tile group of an XCD
+        constexpr int GM = 4;     // row tiles per tile group of an XCD (8 measured the same)
         const int width = GM * tiles_n;
         const int group = idx / width, first_m = group * GM;
         const int gsz = min(tiles_m - first_m, GM);
@@ -1039,15 +1030,8 @@ void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s) {
 }
 
 int gemm_p8_variant(const GemmArgs& g);
-void launch_gemm_p8(const GemmArgs& g_in, hipStream_t s) {
-    if (g_in.M <= 0 || g_in.N <= 0) return;
-    GemmArgs g = g_in;
-    {   // tuning knobs of the 256x256 kernel (environment, read once)
-        static const int stagger_us = getenv("ARTALK_P8_STAGGER_US") ? atoi(getenv("ARTALK_P8_STAGGER_US")) : 0;
-        static const int dma_split = getenv("ARTALK_P8_DMA_SPLIT") ? atoi(getenv("ARTALK_P8_DMA_SPLIT")) : 0;
-        g.stagger_ticks = stagger_us * 100;
-        g.dma_split = dma_split;
-    }
+void launch_gemm_p8(const GemmArgs& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return;
     const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t256 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
     const int t256sq = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     int cfg = g.force_cfg;

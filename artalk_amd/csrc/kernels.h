@@ -47,7 +47,6 @@ struct GemmArgs {
     int splitk = 1; float* partial = nullptr;
     int force_cfg = -1;  // >= 0: tile configuration override (tuning/tests)
     int graph_tag = 0;   // 1 for launches inside the captured AR/VAE body (separate kernel symbol, same code)
-    int stagger_ticks = 0, dma_split = 0;   // gemm_p8_256_kernel tuning (launch_gemm_p8)
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);
 void launch_splitk_reduce(const GemmArgs& g, hipStream_t s);   // epilogue pass of a split-K GEMM (g.splitk > 1)

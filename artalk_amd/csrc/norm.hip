@@ -5,7 +5,6 @@
 //   VAE blocks            LN(512, affine, eps 1e-5)                     app/modules/bitwise_vae.py:203
 //   style encoder         LN(128, affine, eps 1e-5)  (post-LN)          app/modules/style_encoder.py:15-21
 // HBM-bound: each row is read once with 16-byte loads and written once.
-#include <cstdlib>
 #include "common.h"
 
 namespace artalk {
@@ -68,8 +67,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
                 o[e] = apply_act_rt(t, a.act);
             }
             if (VW == 4 && a.out_p8) {
-                if (a.out_p8 == 2) store_p8x4(y, c, o[0], o[1], o[2], o[3]);     // tuning: unpaired 8-byte stores
-                else store_p8x4_pair(y, c, o[0], o[1], o[2], o[3]);              // c = 4 * (64 i + lane): adjacent lanes, adjacent runs
+                store_p8x4_pair(y, c, o[0], o[1], o[2], o[3]);      // c = 4 * (64 i + lane): adjacent lanes, adjacent runs
             } else if (VW == 4) {
                 f32x4 t = {o[0], o[1], o[2], o[3]};
                 *reinterpret_cast<f32x4*>(y + c) = t;
@@ -86,11 +84,8 @@ static void launch_ln(const LnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((layernorm_kernel<D, RPW>), dim3((a.M + rows_per_block - 1) / rows_per_block), dim3(256), 0, s, a);
 }
 
-void launch_layernorm(const LnArgs& a_in, hipStream_t s) {
-    if (a_in.M <= 0) return;
-    LnArgs a = a_in;
-    static const int unpaired = getenv("ARTALK_LN_UNPAIRED") ? atoi(getenv("ARTALK_LN_UNPAIRED")) : 0;   // tuning
-    if (a.out_p8 && unpaired) a.out_p8 = 2;
+void launch_layernorm(const LnArgs& a, hipStream_t s) {
+    if (a.M <= 0) return;
     const bool big = a.M >= 8192;      // several rows per wave only when there are enough rows to fill the chip anyway
     switch (a.D) {
         case 128: launch_ln<128, 1>(a, s); break;

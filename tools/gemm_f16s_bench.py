@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Throughput of the f16x3 split GEMM per shape: tile cfg 0 (128x128) / 1 (64x64) x {fp32 A split in-kernel, pre-packed A}."""
+"""Throughput of the f16x3 split GEMM kernels per shape (GEMM_ONLY="name,..." and GEMM_VARIANTS="cfg:packed,..." select)."""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,8 @@ SHAPES = [("w2v qkv", 19200, 3072, 1024), ("w2v out", 19200, 1024, 1024), ("w2v 
           ("g qkv p3", 800, 2304, 768), ("g proj p3", 800, 768, 768), ("g ffn1 p3", 800, 3072, 768), ("g ffn2 p3", 800, 768, 3072),
           ("g qkv p2", 400, 2304, 768), ("g proj p2", 400, 768, 768), ("g ffn1 p2", 400, 3072, 768), ("g ffn2 p2", 400, 768, 3072),
           ("g qkv p1", 80, 2304, 768), ("g ffn2 p1", 80, 768, 3072), ("g hist kv", 2896, 1536, 768)]
-variants = [(0, 0), (1, 1), (2, 1), (6, 1)]   # (cfg, A packed): 0/1 register-staged 128x128 / 64x64, 2 LDS-DMA 128x128, 6 LDS-DMA 256x128   # (tile cfg, A packed): cfg 2 = LDS-DMA pipelined kernel
+variants = [(1, 1), (2, 1), (7, 1), (8, 1)]   # (cfg, A packed): 0/1 register-staged 128x128 / 64x64; LDS-DMA kernels: 2 128x128, 6 256x128, 7 256x256,
+                                               # 8 two-workgroup 128x128, 20/21/22 small-grid 64x64 / 128x64 / 128x128; cfg | S << 8 = split-K S (8, 20-22)
 only = os.environ.get("GEMM_ONLY")
 if only:
     SHAPES = [x for x in SHAPES if x[0] in only.split(",")]
