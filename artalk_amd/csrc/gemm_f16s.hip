@@ -812,6 +812,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
         constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
+        if constexpr (ABL == 7) { asm volatile("" ::"v"(acc[i][j])); return; }     // timing ablation: no epilogue at all
         if (P) partial_tile32(g, P, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);     // raw sums: splitk_reduce_kernel finishes
         else epilogue_tile32(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);
     };
@@ -1045,6 +1046,7 @@ void launch_gemm_p8(const GemmArgs& g, hipStream_t s) {
         case 7: hipLaunchKernelGGL((gemm_p8_256_kernel<0>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
         case 17: hipLaunchKernelGGL((gemm_p8_256_kernel<6>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
         case 18: hipLaunchKernelGGL((gemm_p8_2wg_kernel<6>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;
+        case 19: hipLaunchKernelGGL((gemm_p8_2wg_kernel<7>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;   // ablation: no epilogue
         default:
             if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wg_kernel<0, 1>), dim3(t128, g.splitk), dim3(256), 2 * 256 * 128, s, g);
             else hipLaunchKernelGGL((gemm_p8_2wg_kernel<0, 0>), dim3(t128, g.splitk), dim3(256), 2 * 256 * 128, s, g);
