@@ -179,6 +179,45 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
         }
     }
 }
+// Store-only form of epilogue_tile32 for a tile whose bias is already added and that has no gate / residual, every lane valid and
+// the 16-byte path available (the deferred epilogue of gemm_p8_2wgp_kernel): activation, then exactly 4 store instructions.
+__device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* C, int row, int col0, int h, f32x16& v) {
+    const long crow = map_row(g.cmap, row);
+    if (g.act != ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = apply_act_rt(v[e], g.act);
+    }
+    if (g.c_p8) {
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+            unsigned int w[2][4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                f16x4_t hh, ll;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f16(v[8 * qp + 4 * k + e] * kActScale, a, b); hh[e] = a; ll[e] = b; }
+                const uint2 hu = __builtin_bit_cast(uint2, hh), lu = __builtin_bit_cast(uint2, ll);
+                w[k][0] = hu.x; w[k][1] = hu.y; w[k][2] = lu.x; w[k][3] = lu.y;
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(w[0][d], w[1][d], false, false);
+                w[0][d] = sw[0]; w[1][d] = sw[1];
+            }
+            unsigned char* o = reinterpret_cast<unsigned char*>(C + crow * g.ldc + col0 + 16 * qp + 8 * h);
+            const u32x4_t hi = {w[0][0], w[0][1], w[1][0], w[1][1]}, lo = {w[0][2], w[0][3], w[1][2], w[1][3]};
+            *reinterpret_cast<u32x4_t*>(o) = hi;
+            *reinterpret_cast<u32x4_t*>(o + 16) = lo;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(C + crow * g.ldc + col0 + 8 * q + 4 * h) = o;
+        }
+    }
+}
+
 // ---- Coalesced epilogue through wave-private LDS (the LDS-DMA kernels, whose LDS is free after the main loop).  The store tail
 // of a tile is bound by vector-memory INSTRUCTIONS whose lanes scatter over many rows (a C^T accumulator tile stores 32 rows x 32 B
 // per instruction: 256 KiB of a 256x256 tile took 33 us); transposed through LDS every instruction covers whole row segments.

@@ -1273,7 +1273,7 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
     g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act; g.force_cfg = force_cfg;
     if (force_cfg >= 2) {   // LDS-DMA pipelined kernel (needs both operands in P8); 3 / 5 select the pipeline depth, 6 = 256x128 tiles, 2 = default
         if (!a_packed) return ARTALK_EINVAL;
-        g.force_cfg = force_cfg == 9 ? -1 : force_cfg;   // 9: the engine's own choice between the production kernels (7 / 8)
+        g.force_cfg = force_cfg == 99 ? -1 : force_cfg;   // 99: the engine's own choice between the production kernels
         if (force_cfg >= 16 && force_cfg <= 18) { g.partial = (float*)bias; g.bias = nullptr; }   // timing build: `bias` carries the stamp buffer (8 x u64 per tile)
         if ((force_cfg & 0xff) >= 20 || ((force_cfg & 0xff) == 8 && (force_cfg >> 8))) {     // 20-22: small-grid LDS-DMA kernel, 8: two-workgroup kernel; bits 8-15: split-K factor (slabs in a temporary)
             g.force_cfg = force_cfg & 0xff;

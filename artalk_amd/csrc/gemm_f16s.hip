@@ -829,6 +829,212 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// Persistent form of the two-workgroup kernel with a DEFERRED epilogue: 512 workgroups (two per CU) walk the tile list with
+// stride 512; a finished tile's 64 result registers (scaled, bias added) are kept and its four 32x32 sub-tiles are finished
+// (activation, P8 split) and stored one per K step during the first four K steps of the NEXT tile, so the stores trickle out
+// under matrix work instead of blocking the CU's memory pipeline in a burst (the store tail costs 13-20 % of a K = 1024 GEMM,
+// DESIGN.md).  Deferred only where it is free of loads and of partial lanes: full tiles, 16-byte aligned rows, no residual, no
+// gate (everything else takes the immediate epilogue).  vmcnt counts loads and stores together in issue order, so the wait at
+// the top of a K step that follows a deferred sub-tile leaves exactly its 4 store instructions in flight.
+template <int TAG = 0>
+__global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;     // 32 KiB
+    constexpr int NDMA = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    const int ntiles = tiles_n * tiles_m;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const int nk = g.K / BK;
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_p8;
+    unsigned a_off[2][2], w_off[2][2];
+    {
+        const int arow = wm * 64 + r, wrow = wn * 64 + r;
+        const int akey = (arow >> 1) & 7, wkey = (wrow >> 1) & 7;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int lo = 0; lo < 2; ++lo) {
+                const int c = (kb * 2 + h) * 2 + lo;
+                a_off[kb][lo] = lds0 + arow * 128 + ((c ^ akey) << 4);
+                w_off[kb][lo] = lds0 + BM * 128 + wrow * 128 + ((c ^ wkey) << 4);
+            }
+    }
+    const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+    const bool can_defer = epi.vec && !g.R && !g.gate && nk >= 4;
+
+    f32x16 acc[2][2], keep[2][2];
+    bool pending = false;
+    int pm0 = 0, pn0 = 0;
+    const unsigned char* src[NDMA];
+    f16x8 bh[2][2], bl[2][2], ah[2], al[2];
+
+    auto issue_piece = [&](int q, int kt, int buf) {
+        unsigned char* dst = smem_p8 + buf * STAGE_BYTES + (q < 4 ? 0 : BM * 128) + (wave * 4 + (q & 3)) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (long)kt * (BK * 4)),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    auto read_b = [&](unsigned sb, int kb) {
+        bh[kb][0] = lds_read128<0>(w_off[kb][0] + sb);
+        bl[kb][0] = lds_read128<0>(w_off[kb][1] + sb);
+        bh[kb][1] = lds_read128<4096>(w_off[kb][0] + sb);
+        bl[kb][1] = lds_read128<4096>(w_off[kb][1] + sb);
+    };
+    auto read_a = [&](unsigned sb, int kb, int i) {
+        const unsigned hp = a_off[kb][0] + sb, lp = a_off[kb][1] + sb;
+        if (i == 0) { ah[0] = lds_read128<0>(hp); al[0] = lds_read128<0>(lp); }
+        else { ah[1] = lds_read128<4096>(hp); al[1] = lds_read128<4096>(lp); }
+    };
+    auto substep = [&](int kt_issue, int buf, unsigned sb, auto issue_tag, auto kb_tag, auto i_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        constexpr int kb = decltype(kb_tag)::value, i = decltype(i_tag)::value;
+        if constexpr (i == 0) { read_a(sb, kb, 1); wait_lgkmcnt<2>(); }
+        else if constexpr (kb == 0) { read_b(sb, 1); read_a(sb, 1, 0); wait_lgkmcnt<6>(); }
+        else wait_lgkmcnt<0>();
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], ah[i], acc[i][j], 0, 0, 0);
+                else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kb][j], ah[i], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], al[i], acc[i][j], 0, 0, 0);
+                const int piece = (kb * 2 + i) * 3 + t;
+                if (ISSUE && j == 1 && piece < NDMA) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_piece(piece, kt_issue, buf ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // behind: vector-memory instructions issued after the DMA pieces of the stage this step reads (0; the 4 stores of the deferred
+    // sub-tile of the previous step; the 16 stores of an immediate full-tile epilogue); dq: sub-tile of the kept tile to finish at the
+    // end of this step (-1: none); kt_issue: K tile (of the tile `src` points at) fetched into the other buffer meanwhile
+    auto kstep = [&](int buf, auto issue_tag, int behind, int dq, int kt_issue) {
+        const unsigned sb = buf * STAGE_BYTES;
+        if (behind == 4) wait_vmcnt<4>(); else if (behind == 16) wait_vmcnt<16>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(sb, 0);
+        read_a(sb, 0, 0);
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        substep(kt_issue, buf, sb, issue_tag, I0{}, I0{});
+        substep(kt_issue, buf, sb, issue_tag, I0{}, I1{});
+        substep(kt_issue, buf, sb, issue_tag, I1{}, I0{});
+        substep(kt_issue, buf, sb, issue_tag, I1{}, I1{});
+        if (dq >= 0) {
+            const int row0 = pm0 + wm * 64 + r, col0 = pn0 + wn * 64;
+            if (dq == 0) epilogue_tile32_store(g, epi.C, row0, col0, h, keep[0][0]);
+            else if (dq == 1) epilogue_tile32_store(g, epi.C, row0, col0 + 32, h, keep[0][1]);
+            else if (dq == 2) epilogue_tile32_store(g, epi.C, row0 + 32, col0, h, keep[1][0]);
+            else epilogue_tile32_store(g, epi.C, row0 + 32, col0 + 32, h, keep[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        const int xcd = t & 7, q = ntiles >> 3, rr = ntiles & 7;
+        const int idx = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
+        constexpr int GM = 4;
+        const int width = GM * tiles_n;
+        const int group = idx / width, first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        const int in_g = idx - group * width;
+        const int tn = in_g / gsz;
+        m0 = (first_m + (in_g - tn * gsz)) * BM;
+        n0 = tn * BN;
+    };
+    auto set_src = [&](int m0, int n0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ra = wave * 32 + q * 8 + prow;
+            const int gm = min(m0 + ra, g.M - 1);
+            const int gn = min(n0 + ra, g.N - 1);
+            const int sw = (pchunk ^ ((ra >> 1) & 7)) << 4;
+            src[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda) * 4 + sw;
+            src[4 + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw) * 4 + sw;
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    int m0, n0;
+    tile_origin(t, m0, n0);
+    set_src(m0, n0);
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) issue_piece(q, 0, 0);
+    int gs = 0, behind = 0;          // running K-step count (ring parity), see kstep
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const int t_next = t + gridDim.x;
+        const bool has_next = t_next < ntiles;
+        int nm0 = 0, nn0 = 0;
+        if (has_next) tile_origin(t_next, nm0, nn0);
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const int dq = (pending && kt < 4) ? kt : -1;
+            kstep(gs & 1, std::true_type{}, behind, dq, kt + 1);
+            behind = dq >= 0 ? 4 : 0;
+            ++gs;
+        }
+        pending = false;
+        // last K step of the tile: the ring runs on into the next tile (its first stage is fetched now; the source pointers of
+        // this tile are no longer needed)
+        if (has_next) { set_src(nm0, nn0); kstep(gs & 1, std::true_type{}, behind, -1, 0); }
+        else kstep(gs & 1, std::false_type{}, behind, -1, 0);
+        ++gs;
+        behind = 0;
+        const bool full = m0 + BM <= g.M && n0 + BN <= g.N;
+        {   // (the launcher takes this kernel only when the 16-byte epilogue path applies: epi.vec)
+            // results move to the kept registers (scaled, bias added); the accumulators are dead from here on
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
+                    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                    if (epi.bias && c < g.N) b = *reinterpret_cast<const f32x4*>(epi.bias + c);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) keep[i][j][4 * q + e] = acc[i][j][4 * q + e] * kOutScale + b[e];
+                }
+            if (can_defer && full) {
+                pending = true; pm0 = m0; pn0 = n0;
+            } else {                 // edge tile, residual or gate: finish it now (bias is already in)
+                EpiCtx e2 = epi;
+                e2.bias = nullptr;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) epilogue_tile32(g, e2, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, keep[i][j]);
+                // a full fp32 tile issued exactly 16 store instructions behind the next tile's first stage (P8 results and
+                // partial tiles: wait for everything)
+                behind = (full && !g.c_p8) ? 16 : 0;
+            }
+        }
+        if (!has_next) break;
+        t = t_next; m0 = nm0; n0 = nn0;
+    }
+    if (pending) {
+        const int row0 = pm0 + wm * 64 + r, col0 = pn0 + wn * 64;
+        epilogue_tile32_store(g, epi.C, row0, col0, h, keep[0][0]);
+        epilogue_tile32_store(g, epi.C, row0, col0 + 32, h, keep[0][1]);
+        epilogue_tile32_store(g, epi.C, row0 + 32, col0, h, keep[1][0]);
+        epilogue_tile32_store(g, epi.C, row0 + 32, col0 + 32, h, keep[1][1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Small-grid variant for the AR/VAE scale steps (M = clips x 1..100 tokens): these launches are bound by the latency of ONE
 // tile, and the register-staged kernel's single K tile of prefetch costs ~1 us per K step (a 64x64 tile over K = 768 took
 // 23-28 us whatever M was).  Here a 64x64 (or 128x64) tile is fed by the same LDS-DMA ring as the big kernels, STAGES-1 K
@@ -1031,12 +1237,21 @@ void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s) {
 }
 
 int gemm_p8_variant(const GemmArgs& g);
+// host-side copy of make_epi()'s test: every row start and every run of 4 columns of C / bias / R / gate is 16-byte aligned
+static bool epi_vec_host(const GemmArgs& g) {
+    unsigned long long bits = (unsigned long long)(g.N | g.ldc) | ((unsigned long long)g.C >> 2);
+    if (g.bias) bits |= (unsigned long long)g.bias >> 2;
+    if (g.R) bits |= (unsigned long long)g.ldr | ((unsigned long long)g.R >> 2);
+    if (g.gate) bits |= (unsigned long long)g.ldg | ((unsigned long long)g.gate >> 2);
+    return (bits & 3) == 0;
+}
 void launch_gemm_p8(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return;
     const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t256 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
     const int t256sq = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     int cfg = g.force_cfg;
     if (cfg < 0) cfg = gemm_p8_variant(g) == 1 ? 7 : 8;
+    static const int persist = getenv("ARTALK_P8_PERSIST") ? atoi(getenv("ARTALK_P8_PERSIST")) : 1;     // tuning: 0 = one workgroup per tile
     switch (cfg) {   // 7 / 8 are the production kernels; the others are kept for tuning (tools/gemm_f16s_bench.py)
         case 2: hipLaunchKernelGGL((gemm_p8_kernel<128, 4>), dim3(t128), dim3(512), 4 * 256 * 128, s, g); break;
         case 3: hipLaunchKernelGGL((gemm_p8_kernel<128, 3>), dim3(t128), dim3(512), 3 * 256 * 128, s, g); break;
@@ -1046,9 +1261,12 @@ void launch_gemm_p8(const GemmArgs& g, hipStream_t s) {
         case 7: hipLaunchKernelGGL((gemm_p8_256_kernel<0>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
         case 17: hipLaunchKernelGGL((gemm_p8_256_kernel<6>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
         case 18: hipLaunchKernelGGL((gemm_p8_2wg_kernel<6>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;
+        case 9: hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, g); break;   // persistent, deferred epilogue
         case 19: hipLaunchKernelGGL((gemm_p8_2wg_kernel<7>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;   // ablation: no epilogue
         default:
             if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wg_kernel<0, 1>), dim3(t128, g.splitk), dim3(256), 2 * 256 * 128, s, g);
+            else if (cfg == 8 && g.force_cfg < 0 && g.splitk == 1 && persist && epi_vec_host(g))     // production choice: persistent, deferred epilogue
+                hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, g);
             else hipLaunchKernelGGL((gemm_p8_2wg_kernel<0, 0>), dim3(t128, g.splitk), dim3(256), 2 * 256 * 128, s, g);
             break;
     }

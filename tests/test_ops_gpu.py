@@ -113,8 +113,8 @@ def test_gemm_p8_dma_pipeline_and_producers():
     assert L.artalk_op_layernorm(_p(dX), _p(Ap), _p(dlw), _p(dlb), None, None, M, K, 1e-5, 0x100, None) == 0
     out = torch.full((M, N), float("nan"), device="cuda")
     # LDS-DMA kernels 128x128 / 256x256 / two-workgroup / 256x128, register-staged 128x128 and 64x64, the small-grid LDS-DMA kernel
-    # (64x64, 128x64, 128x128; 20 | 3 << 8 = split-K 3; 8 | 3 << 8 = the two-workgroup kernel with split-K 3), all fed with the P8 activation
-    for cfg in (2, 7, 8, 6, 0, 1, 20, 21, 22, 20 | (3 << 8), 21 | (5 << 8), 8 | (3 << 8)):
+    # (64x64, 128x64, 128x128; 20 | 3 << 8 = split-K 3; 8 | 3 << 8 = the two-workgroup kernel with split-K 3; 9 = its persistent form with the deferred epilogue), all fed with the P8 activation
+    for cfg in (2, 7, 8, 9, 6, 0, 1, 20, 21, 22, 20 | (3 << 8), 21 | (5 << 8), 8 | (3 << 8)):
         out.fill_(float("nan"))
         assert L.artalk_op_gemm_f16s_packed(_p(Ap), 1, K, _p(Wp), _p(db), _p(out), M, N, K, 0, cfg, None) == 0
         torch.cuda.synchronize()
