@@ -422,7 +422,7 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     Workspace& w = m->ws;
     const int CD = c.w2v_conv_dim, Hs = c.w2v_hidden;
     // f16x3 mode: every activation whose only consumer is a GEMM is written by its producer directly in the P8 split
-    // format (same bytes), so the big GEMMs can stage both operands with LDS-DMA (gemm_p8_kernel).
+    // format (same bytes), so the big GEMMs can stage both operands with LDS-DMA (gemm_p8_2wgp_kernel / gemm_p8_256_kernel).
     const int p8 = m->precision == 1 ? 1 : 0;
     const int AP = p8 ? LF_A_P8 : 0;
     launch_audio_normalize(audio, w.src_off + c0, w.xnorm, n, kSamplesPerChunk, s);

@@ -27,9 +27,9 @@ enum Act { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_TANH = 2, ACT_LEAKY02 = 3 };
 struct GemmArgs {
     const float* A = nullptr; long lda = 0;
     const float* W = nullptr; long ldw = 0;
-    const unsigned int* Wp = nullptr;   // optional packed (f16 hi | f16 lo << 16) copy of W, same ld: f16x3 split path
-    int c_p8 = 0;                        // 1: write C in the P8 split format (the consumer is a split GEMM), gemm_p8_kernel only
-    int a_packed = 0;                    // 1: A already holds packed split words (written by a producer kernel), f16x3 path only
+    const unsigned int* Wp = nullptr;   // optional copy of W in the P8 split format (common.h), same ld: f16x3 split path
+    int c_p8 = 0;                        // 1: write C in the P8 split format (the consumer is a split GEMM); every split-GEMM epilogue and the split-K reduce
+    int a_packed = 0;                    // 1: A is already in the P8 split format (written so by its producer kernel), f16x3 path only
     int exact = 0;                       // 1: decision-critical GEMM (logit / code heads), always on the fp32 MFMA path
     const float* bias = nullptr;
     float* C = nullptr; long ldc = 0; RowMap cmap = {INT_MAX, 0, 0};
@@ -54,9 +54,9 @@ int gemm_tile_count(const GemmArgs& g, bool f16s);             // output tiles o
 // fp32-accurate GEMM on the fp16 matrix cores by operand splitting (gemm_f16s.hip)
 void launch_pack_split(const float* w, unsigned int* out, long n, bool is_weight, hipStream_t s);
 bool gemm_f16s_eligible(const GemmArgs& g);
-int gemm_f16s_config(const GemmArgs& g);     // 0: 128x128 (dominant kernel of the split mode), 1: 64x64
+int gemm_f16s_config(const GemmArgs& g);     // register-staged kernel: 0: 128x128, 1: 64x64
 void launch_gemm_f16s(const GemmArgs& g, hipStream_t s);
-bool gemm_p8_eligible(const GemmArgs& g);      // both operands in P8 and a large grid: LDS-DMA pipelined kernel
+bool gemm_p8_eligible(const GemmArgs& g);      // both operands in P8 and a large grid: the LDS-DMA kernels (gemm_p8_2wgp / _256)
 void launch_gemm_p8(const GemmArgs& g, hipStream_t s);
 int gemm_p8_variant(const GemmArgs& g);
 bool gemm_p8_sm_eligible(const GemmArgs& g);   // both operands in P8, any grid (split-K capable): small-tile LDS-DMA kernel
