@@ -122,7 +122,7 @@ def test_gemm_p8_dma_pipeline_and_producers():
         assert err < 2e-6, (cfg, err)
     # small ragged shapes of the AR scale steps through the small-grid kernel (M = 80 / 400 rows, K = 1024 here)
     for Ms in (80, 400):
-        for cfg in (20, 21, 20 | (4 << 8)):
+        for cfg in (20, 21, 20 | (4 << 8), 9, 8):     # 9 / 8: the large-grid kernels on a grid smaller than the chip (one tile per workgroup)
             o2 = torch.full((Ms, N), float("nan"), device="cuda")
             assert L.artalk_op_gemm_f16s_packed(_p(Ap), 1, K, _p(Wp), _p(db), _p(o2), Ms, N, K, 0, cfg, None) == 0
             torch.cuda.synchronize()
