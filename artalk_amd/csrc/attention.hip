@@ -370,7 +370,10 @@ __device__ __forceinline__ void split4(const f32x4 x, f16x4_t& hi, f16x4_t& lo) 
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const _Float16 a = (_Float16)x[e]; hi[e] = a; lo[e] = (_Float16)(x[e] - (float)a); }
 }
-template <int FASTEXP>
+// QKVP8: Q, K and V arrive already in the P8 split format (x16, hi | lo per 8 elements: common.h), written by the qkv GEMM's
+// epilogue: the fragments and the LDS images are then plain copies (no conversion: the staging VALU work was ~40 % of this kernel's);
+// the x16 of q and k is taken out of the scores together with the softmax scale, the x16 of v out of the final normalisation.
+template <int FASTEXP, int QKVP8 = 0>
 __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a) {
     constexpr int HD = 64, KB = 64, PB = 160;      // keys per block, bytes per LDS row (64 halves + pad)
     __shared__ __attribute__((aligned(16))) unsigned char Kh[KB * PB], Kl[KB * PB], Vh[KB * PB], Vl[KB * PB];
@@ -386,7 +389,15 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
 
     // ---- Q fragments (B operand of S^T): lane (r, g) holds Q[qi][8g + 32kb .. +7], split ----
     h8_t qh[2], ql[2];
-    {
+    if constexpr (QKVP8) {
+        const unsigned char* qp = reinterpret_cast<const unsigned char*>(a.Q + (long)b * a.q_bstride + (long)qi * a.ldq + h * HD);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            qh[kb] = qvalid ? *reinterpret_cast<const h8_t*>(qp + (g + 4 * kb) * 32) : z;          // 8-element group g + 4 kb: 16 B hi, 16 B lo
+            ql[kb] = qvalid ? *reinterpret_cast<const h8_t*>(qp + (g + 4 * kb) * 32 + 16) : z;
+        }
+    } else {
         const float* qp = a.Q + (long)b * a.q_bstride + (long)qi * a.ldq + h * HD;
         f32x4 x[2][2];
 #pragma unroll
@@ -424,6 +435,7 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
             ql[kb] = h8_t{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
         }
     }
+    const float sfix = QKVP8 ? a.scale / (kActScale * kActScale) : 1.0f;      // scores of P8 operands carry 16 * 16 and no softmax scale yet
     const int klim = (a.split_q > 0 && qi < a.split_q) ? a.split_k : a.Lk;
     const int qblk_last = min(qblk0 + 63, a.Lq - 1);
     const int lk_wg = (a.split_q > 0 && qblk_last < a.split_q) ? a.split_k : a.Lk;
@@ -440,6 +452,25 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
 
     for (int kb0 = 0; kb0 < lk_wg; kb0 += KB) {
         __syncthreads();
+        if constexpr (QKVP8) {
+#pragma unroll
+            for (int i = 0; i < KB * 8 / 256; ++i) {      // one 8-element group (16 B hi + 16 B lo) of K and of V per thread and pass
+                const int idx = tid + i * 256;
+                const int row = idx >> 3, g8 = idx & 7;
+                const int kr = kb0 + row;
+                h8_t kh = {0, 0, 0, 0, 0, 0, 0, 0}, kl = kh, vh = kh, vl = kh;
+                if (kr < a.Lk) {
+                    const unsigned char* kp = reinterpret_cast<const unsigned char*>(Kb + (long)kr * a.ldk) + g8 * 32;
+                    const unsigned char* vp = reinterpret_cast<const unsigned char*>(Vb + (long)kr * a.ldv) + g8 * 32;
+                    kh = *reinterpret_cast<const h8_t*>(kp); kl = *reinterpret_cast<const h8_t*>(kp + 16);
+                    vh = *reinterpret_cast<const h8_t*>(vp); vl = *reinterpret_cast<const h8_t*>(vp + 16);
+                }
+                *reinterpret_cast<h8_t*>(Kh + row * PB + g8 * 16) = kh;
+                *reinterpret_cast<h8_t*>(Kl + row * PB + g8 * 16) = kl;
+                *reinterpret_cast<h8_t*>(Vh + row * PB + g8 * 16) = vh;
+                *reinterpret_cast<h8_t*>(Vl + row * PB + g8 * 16) = vl;
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < KB * 16 / 256; ++i) {
             const int idx = tid + i * 256;
@@ -465,6 +496,7 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
             split4(vv, hh, ll);
             *reinterpret_cast<f16x4_t*>(Vh + row * PB + c4 * 2) = hh;
             *reinterpret_cast<f16x4_t*>(Vl + row * PB + c4 * 2) = ll;
+        }
         }
         __syncthreads();
         if (!wave_active) continue;      // wave-uniform: EXEC stays all ones for the transposed reads below
@@ -492,7 +524,7 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int kidx = kb0 + t * 16 + 4 * g + j;
-                const float sv = (kidx < klim) ? st[t][j] : -INFINITY;
+                const float sv = (kidx < klim) ? (QKVP8 ? st[t][j] * sfix : st[t][j]) : -INFINITY;
                 st[t][j] = sv;
                 mx = fmaxf(mx, sv);
             }
@@ -548,7 +580,7 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (qvalid) {
-        const float inv = 1.0f / l;
+        const float inv = QKVP8 ? 1.0f / (l * kActScale) : 1.0f / l;      // P8 values carry x16
         float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -563,14 +595,16 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
 void launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.Lq <= 0) return;
     static const int short_lq = getenv("ARTALK_ATTN_SHORT_LQ") ? atoi(getenv("ARTALK_ATTN_SHORT_LQ")) : 64;   // tuning
-    if (a.HD == 64 && a.split_q == 0 && a.Lq <= short_lq && a.Lk >= 64) {
+    if (a.HD == 64 && a.split_q == 0 && a.Lq <= short_lq && a.Lk >= 64 && !a.qkv_p8) {
         hipLaunchKernelGGL(attention_short_kernel<64>, dim3((a.Lq + 15) / 16, a.H, a.B), dim3(256), 0, s, a);
         return;
     }
     dim3 grid((a.Lq + 63) / 64, a.H, a.B), block(256);
     // v_exp_f32-based exp (1.2e-6 relative at |x| = 20, where p = 2e-9) by default: 154 -> 137 us per wav2vec2 layer; the fp32 kernels keep expf
     static const int fastexp = getenv("ARTALK_ATTN_FASTEXP") ? atoi(getenv("ARTALK_ATTN_FASTEXP")) : 1;
-    if (a.HD == 64 && a.split16 && fastexp)
+    if (a.HD == 64 && a.split16 && a.qkv_p8 && !a.l2norm)
+        hipLaunchKernelGGL((attention_f16_kernel<1, 1>), grid, block, 0, s, a);
+    else if (a.HD == 64 && a.split16 && fastexp)
         hipLaunchKernelGGL(attention_f16_kernel<1>, grid, block, 0, s, a);
     else if (a.HD == 64 && a.split16)
         hipLaunchKernelGGL(attention_f16_kernel<0>, grid, block, 0, s, a);

@@ -458,8 +458,9 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     for (int i = 0; i < c.w2v_layers; ++i) {
         const W2VLayer& L = m->w2v[i];
         layernorm(h, w.xln, L.ln1w, L.ln1b, M, Hs, c.w2v_ln_eps, ACT_NONE, s, p8);
-        linear(m, w.xln, Hs, L.qkv_w, L.qkv_b, w.qkv, 3 * Hs, M, 3 * Hs, Hs, ACT_NONE, nullptr, s, AP);
+        linear(m, w.xln, Hs, L.qkv_w, L.qkv_b, w.qkv, 3 * Hs, M, 3 * Hs, Hs, ACT_NONE, nullptr, s, AP | (p8 ? LF_C_P8 : 0));   // q, k, v leave in P8
         AttnArgs a;
+        a.qkv_p8 = p8;
         a.Q = w.qkv; a.K = w.qkv + Hs; a.V = w.qkv + 2 * Hs;
         a.ldq = a.ldk = a.ldv = 3 * Hs; a.q_bstride = a.k_bstride = a.v_bstride = (long)m->Ts * 3 * Hs;
         a.O = w.att; a.ldo = Hs; a.o_bstride = (long)m->Ts * Hs;
@@ -517,8 +518,9 @@ void run_vae_stack(artalk_model* m, const VAESide& S, int B, int T, int split, h
     for (int i = 0; i < c.vae_depth; ++i) {
         const VAELayer& L = S.layers[i];
         layernorm(w.vh, w.vln, L.lnw, L.lnb, M, H, 1e-5f, ACT_NONE, s, p8);
-        linear(m, w.vln, H, L.qkv_w, nullptr, w.vqkv, 3 * H, M, 3 * H, H, ACT_NONE, nullptr, s, AP);
+        linear(m, w.vln, H, L.qkv_w, nullptr, w.vqkv, 3 * H, M, 3 * H, H, ACT_NONE, nullptr, s, AP | (p8 ? LF_C_P8 : 0));   // q, k, v leave in P8
         AttnArgs a;
+        a.qkv_p8 = p8;
         a.Q = w.vqkv; a.K = w.vqkv + H; a.V = w.vqkv + 2 * H; a.ldq = a.ldk = a.ldv = 3 * H;
         a.q_bstride = a.k_bstride = a.v_bstride = (long)T * 3 * H;
         a.O = w.vatt; a.ldo = H; a.o_bstride = (long)T * H;
@@ -1317,6 +1319,7 @@ int artalk_op_attention(const float* Q, const float* K, const float* V, float* O
     if (!Q || !K || !V || !O || (HD != 64 && HD != 32) || ((l2norm & 1) && !qscale)) return ARTALK_EINVAL;
     AttnArgs a;
     a.split16 = (l2norm >> 1) & 1;      // l2norm | 2: the fp16 operand-split kernel of f16x3 mode
+    a.qkv_p8 = (l2norm >> 2) & 1;       // l2norm | 4 (with | 2, without L2 norm): Q, K, V are given in the P8 split format
     l2norm &= 1;
     const long D = (long)H * HD;
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = a.ldk = a.ldv = a.ldo = D;

@@ -90,6 +90,7 @@ struct AttnArgs {
     int split_q = 0, split_k = 0;                    // queries < split_q see keys < split_k only (VAE mask)
     int out_p8 = 0;                                  // 1: write O in the P8 split format
     int split16 = 0;                                 // 1: fp16 operand-split MFMAs (f16x3 mode), 0: exact fp32 MFMAs
+    int qkv_p8 = 0;                                  // 1 (with split16, no l2norm): Q, K, V rows are in the P8 split format (written so by the qkv GEMM)
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 

@@ -158,7 +158,7 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
 int artalk_op_layernorm(const float* X, float* Y, const float* w, const float* b, const float* scale, const float* shift,
                         int M, int D, float eps, int act, void* stream);
 /* Q,K,V,O: [B][L][H*HD] contiguous; l2norm bit 0 -> q,k normalised, q *= qscale[h]; bit 1 -> the fp16 operand-split kernel of
- * f16x3 mode (HD = 64); split: queries<split see keys<split */
+ * f16x3 mode (HD = 64); bit 2 (with bit 1, without bit 0) -> Q, K, V are given in the P8 split format; split: queries<split see keys<split */
 int artalk_op_attention(const float* Q, const float* K, const float* V, float* O, int B, int H, int HD, int Lq, int Lk,
                         float scale, int l2norm, const float* qscale, int split, void* stream);
 /* audio [C][n] -> normalised -> conv0+LN+GELU: Y [C][T][512], T = (n-10)/5+1 */

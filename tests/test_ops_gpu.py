@@ -215,6 +215,17 @@ def test_attention(B, H, HD, Lq, Lk, l2norm, split):
         err16 = (out.cpu() - ref).abs().max().item()
         print(f"attention fp32-mfma err {err:.2e}  f16-split err {err16:.2e}")
         assert err16 < 2e-5, err16
+        if not l2norm:      # the same kernel fed with P8 operands (what the wav2vec2 qkv GEMM hands over)
+            pk = []
+            for t in (dQ, dK, dV):
+                o = torch.empty_like(t, dtype=torch.int32)
+                assert L.artalk_op_pack_split(_p(t), _p(o), t.numel(), 0, None) == 0
+                pk.append(o)
+            out.fill_(float("nan"))
+            assert L.artalk_op_attention(_p(pk[0]), _p(pk[1]), _p(pk[2]), _p(out), B, H, HD, Lq, Lk, scale, 2 | 4, None, split, None) == 0
+            torch.cuda.synchronize()
+            errp = (out.cpu() - ref).abs().max().item()
+            assert errp < 2e-5, errp
 
 
 def test_w2v_front():

@@ -15,7 +15,7 @@ for name, B, H, HD, Lq, Lk, l2, split in [("w2v", 96, 16, 64, 199, 199, 0, 0), (
     O = torch.empty(B, Lq, D, device="cuda"); qs = torch.ones(H, device="cuda")
     fl = 4.0 * B * H * Lq * Lk * HD
     line = f"{name:8s} B={B} H={H} Lq={Lq} Lk={Lk}:"
-    for mode, tag in ((l2, "fp32 mfma"), (l2 | 2, "f16 split")):
+    for mode, tag in ((l2, "fp32 mfma"), (l2 | 2, "f16 split")) + (((2 | 4, "f16 split, P8 in (timing only)"),) if not l2 else ()):
         best = 1e9
         for _ in range(3):
             L.artalk_op_attention(p(Q), p(K), p(V), p(O), B, H, HD, Lq, Lk, 0.125, mode, p(qs), split, s)
