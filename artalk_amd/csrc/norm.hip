@@ -37,10 +37,45 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
             }
         }
     }
+    // affine / modulation vectors are fetched as 16-byte vectors BEFORE the reductions, so their latency (the AdaLN rows come out
+    // of a 1.3 GB table) hides behind the row statistics instead of showing in front of the stores
+    float wv[NV], bv[NV];
+    if (a.w) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = (i * 64 + lane) * VW;
+            if (VW == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(a.w + c), u = *reinterpret_cast<const f32x4*>(a.b + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wv[i * VW + e] = t[e]; bv[i * VW + e] = u[e]; }
+            } else {
+                const float2 t = *reinterpret_cast<const float2*>(a.w + c), u = *reinterpret_cast<const float2*>(a.b + c);
+                wv[i * VW] = t.x; wv[i * VW + 1] = t.y; bv[i * VW] = u.x; bv[i * VW + 1] = u.y;
+            }
+        }
+    }
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const int row = row0 + rr;
         if (row >= a.M) break;
+        float scv[NV], shv[NV];
+        if (a.scale) {
+            const long mr = map_row(a.mmap, row);
+            const float* sc = a.scale + mr * a.ldm;
+            const float* sh = a.shift + mr * a.ldm;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int c = (i * 64 + lane) * VW;
+                if (VW == 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(sc + c), u = *reinterpret_cast<const f32x4*>(sh + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { scv[i * VW + e] = t[e]; shv[i * VW + e] = u[e]; }
+                } else {
+                    const float2 t = *reinterpret_cast<const float2*>(sc + c), u = *reinterpret_cast<const float2*>(sh + c);
+                    scv[i * VW] = t.x; scv[i * VW + 1] = t.y; shv[i * VW] = u.x; shv[i * VW + 1] = u.y;
+                }
+            }
+        }
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) s += v[rr][i];
@@ -49,11 +84,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) { const float d = v[rr][i] - mean; q += d * d; }
         const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + a.eps);
-        const float* sc = nullptr; const float* sh = nullptr;
-        if (a.scale) {
-            const long mr = map_row(a.mmap, row);
-            sc = a.scale + mr * a.ldm; sh = a.shift + mr * a.ldm;
-        }
         float* y = a.Y + (long)row * a.ldy;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -62,8 +92,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
 #pragma unroll
             for (int e = 0; e < VW; ++e) {
                 float t = (v[rr][i * VW + e] - mean) * rstd;
-                if (a.w) t = t * a.w[c + e] + a.b[c + e];
-                if (sc) t = t * (sc[c + e] + 1.0f) + sh[c + e];
+                if (a.w) t = t * wv[i * VW + e] + bv[i * VW + e];
+                if (a.scale) t = t * (scv[i * VW + e] + 1.0f) + shv[i * VW + e];
                 o[e] = apply_act_rt(t, a.act);
             }
             if (VW == 4 && a.out_p8) {
