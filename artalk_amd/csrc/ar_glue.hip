@@ -147,8 +147,8 @@ void launch_vq_embed(const float* feat, int n, const float* We, const float* be,
 __global__ __launch_bounds__(256) void dec_input_kernel(const float* __restrict__ prev_fdec, const float* __restrict__ fhat,
                                                         const uint8_t* __restrict__ bits, const float* __restrict__ dpos,
                                                         float* __restrict__ X) {
-    const int b = blockIdx.x;
-    for (int idx = threadIdx.x; idx < 2 * T100 * CD; idx += 256) {
+    const int b = blockIdx.x;     // grid.y slices of the clip's 6 400 elements: one block per clip was a 25-iteration latency chain
+    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < 2 * T100 * CD; idx += gridDim.y * 256) {
         const int t = idx / CD, c = idx % CD;
         float v;
         if (t < T100) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void dec_input_kernel(const float* __restrict_
 }
 void launch_dec_input(const float* prev_fdec, const float* fhat, const uint8_t* bits, const float* dpos, float* X, int B,
                       hipStream_t s) {
-    hipLaunchKernelGGL(dec_input_kernel, dim3(B), dim3(256), 0, s, prev_fdec, fhat, bits, dpos, X);
+    hipLaunchKernelGGL(dec_input_kernel, dim3(B, 8), dim3(256), 0, s, prev_fdec, fhat, bits, dpos, X);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void dec_finish_kernel(const float* __restrict
                                                          float* __restrict__ out, long out_bstride, int chunk,
                                                          float* __restrict__ E, int MD, int EK, int* __restrict__ status) {
     const int b = blockIdx.x;
-    for (int idx = threadIdx.x; idx < T100 * EK; idx += 256) {
+    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < T100 * EK; idx += gridDim.y * 256) {
         const int t = idx / EK, j = idx % EK;
         float e = 0.f;
         if (j < MD) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void dec_finish_kernel(const float* __restrict
 }
 void launch_dec_finish(const float* dec, const float* mean, const float* stdv, const float* epos, float* out,
                        long out_bstride, int chunk, float* E, int B, hipStream_t s, int* status) {
-    hipLaunchKernelGGL(dec_finish_kernel, dim3(B), dim3(256), 0, s, dec, mean, stdv, epos, out, out_bstride, chunk, E, 106, 128, status);
+    hipLaunchKernelGGL(dec_finish_kernel, dim3(B, 10), dim3(256), 0, s, dec, mean, stdv, epos, out, out_bstride, chunk, E, 106, 128, status);
 }
 
 __global__ __launch_bounds__(256) void enc_input_zero_kernel(const float* __restrict__ mean, const float* __restrict__ stdv,
