@@ -12,6 +12,7 @@
 #include "common.h"
 #include <cmath>
 #include <mutex>
+#include <set>
 
 namespace artalk {
 
@@ -27,33 +28,41 @@ __constant__ float c_hq;               // 1/sqrt(32)
 
 static const int h_pn[NLV] = {1, 5, 25, 50, 100};
 
-void init_ms_tables() {
-    static std::once_flag once;
-    std::call_once(once, [] {
-        int off[NLV + 1] = {0};
-        for (int i = 0; i < NLV; ++i) off[i + 1] = off[i] + h_pn[i];
-        int i0[4][T100], i1[4][T100];
-        float w1[4][T100];
-        for (int p = 0; p < 4; ++p) {
-            const int in = h_pn[p];
-            const float scale = (float)in / (float)T100;     // ATen area_pixel_compute_scale
-            for (int t = 0; t < T100; ++t) {
-                float src = scale * ((float)t + 0.5f) - 0.5f;   // area_pixel_compute_source_index
-                if (src < 0.f) src = 0.f;
-                const int a = (int)src;
-                i0[p][t] = a;
-                i1[p][t] = a + ((a < in - 1) ? 1 : 0);
-                w1[p][t] = src - (float)a;
-            }
+// __constant__ symbols exist once per DEVICE: the tables are uploaded the first time a model is created on each GPU
+// (artalk_create calls this after hipSetDevice).  Returns 0, or -1 with nothing recorded if an upload failed.
+int init_ms_tables() {
+    static std::mutex mu;
+    static std::set<int> ready;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lock(mu);
+    if (ready.count(dev)) return 0;
+    int off[NLV + 1] = {0};
+    for (int i = 0; i < NLV; ++i) off[i + 1] = off[i] + h_pn[i];
+    int i0[4][T100], i1[4][T100];
+    float w1[4][T100];
+    for (int p = 0; p < 4; ++p) {
+        const int in = h_pn[p];
+        const float scale = (float)in / (float)T100;     // ATen area_pixel_compute_scale
+        for (int t = 0; t < T100; ++t) {
+            float src = scale * ((float)t + 0.5f) - 0.5f;   // area_pixel_compute_source_index
+            if (src < 0.f) src = 0.f;
+            const int a = (int)src;
+            i0[p][t] = a;
+            i1[p][t] = a + ((a < in - 1) ? 1 : 0);
+            w1[p][t] = src - (float)a;
         }
-        const float hq = 1.0f / (float)std::sqrt(32.0);
-        hipMemcpyToSymbol(HIP_SYMBOL(c_pn), h_pn, sizeof(h_pn));
-        hipMemcpyToSymbol(HIP_SYMBOL(c_off), off, sizeof(off));
-        hipMemcpyToSymbol(HIP_SYMBOL(c_up_i0), i0, sizeof(i0));
-        hipMemcpyToSymbol(HIP_SYMBOL(c_up_i1), i1, sizeof(i1));
-        hipMemcpyToSymbol(HIP_SYMBOL(c_up_w1), w1, sizeof(w1));
-        hipMemcpyToSymbol(HIP_SYMBOL(c_hq), &hq, sizeof(hq));
-    });
+    }
+    const float hq = 1.0f / (float)std::sqrt(32.0);
+    bool ok = hipMemcpyToSymbol(HIP_SYMBOL(c_pn), h_pn, sizeof(h_pn)) == hipSuccess;
+    ok = ok && hipMemcpyToSymbol(HIP_SYMBOL(c_off), off, sizeof(off)) == hipSuccess;
+    ok = ok && hipMemcpyToSymbol(HIP_SYMBOL(c_up_i0), i0, sizeof(i0)) == hipSuccess;
+    ok = ok && hipMemcpyToSymbol(HIP_SYMBOL(c_up_i1), i1, sizeof(i1)) == hipSuccess;
+    ok = ok && hipMemcpyToSymbol(HIP_SYMBOL(c_up_w1), w1, sizeof(w1)) == hipSuccess;
+    ok = ok && hipMemcpyToSymbol(HIP_SYMBOL(c_hq), &hq, sizeof(hq)) == hipSuccess;
+    if (!ok) return -1;
+    ready.insert(dev);
+    return 0;
 }
 
 __device__ __forceinline__ float up_lin(const float* src /*[pn][32] in LDS*/, int p, int t, int c) {
@@ -287,12 +296,16 @@ void launch_add_row(float* X, const float* v, int M, int D, hipStream_t s) {
 __global__ __launch_bounds__(256) void style_finish_kernel(const float* __restrict__ feat, const float* __restrict__ Ws,
                                                            const float* __restrict__ bs, const float* __restrict__ null_cond,
                                                            const uint8_t* __restrict__ has_style, float* __restrict__ style_cond,
-                                                           int L, int S, int E) {
+                                                           int L, int S, int E, const float* __restrict__ cached, long cached_stride) {
     __shared__ float m[128];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const bool has = has_style ? has_style[b] != 0 : false;
-    if (!has) {
+    const int has = has_style ? has_style[b] : 0;
+    if (has == 0) {
         for (int e = tid; e < E; e += 256) style_cond[(long)b * E + e] = null_cond[e];
+        return;
+    }
+    if (has == 2) {     // row b of the style input carries a condition computed earlier by artalk_style_encode
+        for (int e = tid; e < E; e += 256) style_cond[(long)b * E + e] = cached[(long)b * cached_stride + e];
         return;
     }
     if (tid < S) {
@@ -309,8 +322,9 @@ __global__ __launch_bounds__(256) void style_finish_kernel(const float* __restri
     }
 }
 void launch_style_finish(const float* feat, const float* Ws, const float* bs, const float* null_cond,
-                         const uint8_t* has_style, float* style_cond, int B, hipStream_t s) {
-    hipLaunchKernelGGL(style_finish_kernel, dim3(B), dim3(256), 0, s, feat, Ws, bs, null_cond, has_style, style_cond, 50, 128, 768);
+                         const uint8_t* has_style, float* style_cond, int B, hipStream_t s, const float* cached, long cached_stride) {
+    hipLaunchKernelGGL(style_finish_kernel, dim3(B), dim3(256), 0, s, feat, Ws, bs, null_cond, has_style, style_cond, 50, 128, 768,
+                       cached, cached_stride);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -132,8 +132,16 @@ struct artalk_model {
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
     int branches = 0;                 // 0 = automatic (2 for B >= 8), else forced 1/2/4
     hipStream_t own_stream = nullptr;   // used when the caller passes stream == NULL (graph capture needs a real stream)
-    // graphs: one per active batch size
+    // graphs: one per (active batch size, clip group, precision)
     std::map<int, hipGraphExec_t> graphs;
+    // Pinned host staging for the small per-call tables (chunk offsets, style flags): a ring of slots, each guarded by an event
+    // recorded after its H2D copies, so artalk_infer never has to wait for its own copies (it blocks only if kStageSlots calls
+    // are still in flight).  h_status receives the device status word at the end of every call (async), status_ev marks it.
+    static constexpr int kStageSlots = 4;
+    struct Stage { long* src = nullptr; uint8_t* has = nullptr; hipEvent_t done = nullptr; bool used = false; };
+    Stage stage[kStageSlots];
+    int stage_cap_c = 0, stage_cap_b = 0, stage_next = 0;
+    int* h_status = nullptr; hipEvent_t status_ev = nullptr; bool status_pending = false;
 };
 
 namespace {
@@ -480,11 +488,13 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     stage_mark(m, s, PB_ENC);
 }
 
-void run_style(artalk_model* m, const float* style_motion, int B, hipStream_t s) {
+// style_motion rows: a (50,106) clip where the host flag is 1, a cached 768-float condition where it is 2 (artalk_style_encode);
+// `encode` = some row has flag 1 (the host knows: has_style is a host array), otherwise the encoder stack is skipped altogether
+void run_style(artalk_model* m, const float* style_motion, int B, hipStream_t s, bool encode = true) {
     const artalk_config& c = m->cfg;
     Workspace& w = m->ws;
     const int S = c.style_dim, L = c.style_len, M = B * L;
-    if (style_motion) {
+    if (style_motion && encode) {
         launch_style_input(style_motion, m->st_mean, m->st_std, w.s_in, B, s);
         linear(m, w.s_in, 128, m->st_proj_w, m->st_proj_b, w.s_h, S, M, S, 128, ACT_NONE, nullptr, s);
         launch_add_row(w.s_h, m->st_pe, M, S, s);   // PositionalEncoding quirk: pe[:, seq_len] added to every token
@@ -505,7 +515,8 @@ void run_style(artalk_model* m, const float* style_motion, int B, hipStream_t s)
             layernorm(w.s_tmp, w.s_h, Ly.n2w, Ly.n2b, M, S, 1e-5f, ACT_NONE, s);
         }
     }
-    launch_style_finish(w.s_h, m->sc_w, m->sc_b, m->null_style, style_motion ? w.has_style : nullptr, w.style_cond, B, s);
+    launch_style_finish(w.s_h, m->sc_w, m->sc_b, m->null_style, style_motion ? w.has_style : nullptr, w.style_cond, B, s,
+                        style_motion, (long)L * c.motion_dim);
 }
 
 // one VAE transformer stack (app/modules/bitwise_vae.py:149-157 / :183-191) on B sequences of T tokens, in place on ws.vh
@@ -695,7 +706,7 @@ int run_chunk_body_graphs(artalk_model* m, int B, hipStream_t s) {
     hipStream_t st[4] = {s, m->side_stream[0], m->side_stream[1], m->side_stream[2]};
     for (int h = 0; h < NS; ++h) {
         views[h] = clip_view(m, b0[h], h);
-        const int key = (B * 8 + NS) * 4 + h;
+        const int key = ((B * 8 + NS) * 4 + h) * 2 + m->precision;
         if (m->graphs.find(key) != m->graphs.end()) continue;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
@@ -714,7 +725,7 @@ int run_chunk_body_graphs(artalk_model* m, int B, hipStream_t s) {
         HIPCHK(m, hipEventRecord(m->fork_ev, s));
         for (int h = 1; h < NS; ++h) HIPCHK(m, hipStreamWaitEvent(st[h], m->fork_ev, 0));
     }
-    for (int h = 0; h < NS; ++h) HIPCHK(m, hipGraphLaunch(m->graphs[(B * 8 + NS) * 4 + h], st[h]));
+    for (int h = 0; h < NS; ++h) HIPCHK(m, hipGraphLaunch(m->graphs[((B * 8 + NS) * 4 + h) * 2 + m->precision], st[h]));
     for (int h = 1; h < NS; ++h) {
         HIPCHK(m, hipEventRecord(m->join_ev[h - 1], st[h]));
         HIPCHK(m, hipStreamWaitEvent(s, m->join_ev[h - 1], 0));
@@ -722,9 +733,50 @@ int run_chunk_body_graphs(artalk_model* m, int B, hipStream_t s) {
     return ARTALK_OK;
 }
 
+void free_stage(artalk_model* m) {
+    for (auto& st : m->stage) {
+        if (st.src) (void)hipHostFree(st.src);
+        if (st.has) (void)hipHostFree(st.has);
+        st.src = nullptr; st.has = nullptr; st.used = false;
+    }
+    m->stage_cap_c = m->stage_cap_b = 0;
+}
+int ensure_stage(artalk_model* m, int maxB, int maxC) {
+    if (!m->h_status) {
+        HIPCHK(m, hipHostMalloc(reinterpret_cast<void**>(&m->h_status), 4 * sizeof(int), hipHostMallocDefault));
+        std::memset(m->h_status, 0, 4 * sizeof(int));
+        HIPCHK(m, hipEventCreateWithFlags(&m->status_ev, hipEventDisableTiming));
+    }
+    if (maxB <= m->stage_cap_b && maxC <= m->stage_cap_c) return ARTALK_OK;
+    for (auto& st : m->stage) if (st.used) HIPCHK(m, hipEventSynchronize(st.done));
+    free_stage(m);
+    for (auto& st : m->stage) {
+        HIPCHK(m, hipHostMalloc(reinterpret_cast<void**>(&st.src), (size_t)maxC * sizeof(long), hipHostMallocDefault));
+        HIPCHK(m, hipHostMalloc(reinterpret_cast<void**>(&st.has), (size_t)maxB, hipHostMallocDefault));
+        if (!st.done) HIPCHK(m, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    }
+    m->stage_cap_b = maxB; m->stage_cap_c = maxC;
+    return ARTALK_OK;
+}
+// next slot of the ring; waits only if the call that last used it has not consumed its copies yet
+int next_stage(artalk_model* m, artalk_model::Stage** out) {
+    artalk_model::Stage& st = m->stage[m->stage_next];
+    m->stage_next = (m->stage_next + 1) % artalk_model::kStageSlots;
+    if (st.used) HIPCHK(m, hipEventSynchronize(st.done));
+    *out = &st;
+    return ARTALK_OK;
+}
+// end of a call: hand the device status word to the host asynchronously (artalk_get_status / artalk_poll_status read it)
+int publish_status(artalk_model* m, hipStream_t s) {
+    HIPCHK(m, hipMemcpyAsync(m->h_status, m->ws.status, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(m, hipEventRecord(m->status_ev, s));
+    m->status_pending = true;
+    return ARTALK_OK;
+}
+
 int reserve(artalk_model* m, int maxB, int maxC) {
     const artalk_config& c = m->cfg;
-    if (maxB <= m->ws.maxB && maxC <= m->ws.maxC) return ARTALK_OK;
+    if (maxB <= m->ws.maxB && maxC <= m->ws.maxC) return ensure_stage(m, m->ws.maxB, m->ws.maxC);
     // grow: drop the old workspace (and the graphs that captured its pointers) and allocate the larger one
     maxB = std::max(maxB, m->ws.maxB); maxC = std::max(maxC, m->ws.maxC);
     (void)hipDeviceSynchronize();
@@ -733,6 +785,8 @@ int reserve(artalk_model* m, int maxB, int maxC) {
     for (void* p : m->ws_allocs) if (p) (void)hipFree(p);
     m->ws_allocs.clear();
     m->ws = Workspace();
+    m->stream_B = 0;          // the streaming history lived in the workspace that was just dropped: a session must begin again
+    m->status_pending = false;
     Workspace& w = m->ws;
     const int CD = c.w2v_conv_dim, Hs = c.w2v_hidden;
     w.maxB = maxB; w.maxC = maxC; w.G = std::min(maxC, 96);
@@ -772,7 +826,7 @@ int reserve(artalk_model* m, int maxB, int maxC) {
         if (!p) return fail(m, ARTALK_EHIP, "hipMalloc failed while reserving workspace");
     // the zero fills above run on the null stream; callers use non-blocking streams, which do not order against it
     HIPCHK(m, hipDeviceSynchronize());
-    return ARTALK_OK;
+    return ensure_stage(m, maxB, maxC);
 }
 
 }  // namespace
@@ -808,7 +862,7 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
         }
     }
     for (int i = 0; i < 5; ++i) { m->pn[i] = c.patch_nums[i]; m->off[i + 1] = m->off[i] + c.patch_nums[i]; }
-    init_ms_tables();
+    if (init_ms_tables() != 0) { g_create_error = "uploading the interpolation tables to the device failed"; delete m; return ARTALK_EHIP; }
     const int rc = build_registry(m);
     if (rc != ARTALK_OK) { g_create_error = m->err; artalk_destroy(m); return rc; }
     *out = m;
@@ -830,6 +884,10 @@ void artalk_destroy(artalk_model* m) {
         if (m->join_ev[i]) (void)hipEventDestroy(m->join_ev[i]);
     }
     if (m->fork_ev) (void)hipEventDestroy(m->fork_ev);
+    free_stage(m);
+    for (auto& st : m->stage) if (st.done) (void)hipEventDestroy(st.done);
+    if (m->h_status) (void)hipHostFree(m->h_status);
+    if (m->status_ev) (void)hipEventDestroy(m->status_ev);
     for (void* p : m->allocs) if (p) (void)hipFree(p);
     for (void* p : m->ws_allocs) if (p) (void)hipFree(p);
     delete m;
@@ -973,13 +1031,7 @@ int64_t artalk_weight_bytes(const artalk_model* m) { return m ? m->weight_bytes 
 int artalk_set_profiling(artalk_model* m, int level) { if (!m || level < 0 || level > 2) return ARTALK_EINVAL; m->profiling = level; return ARTALK_OK; }
 int artalk_set_precision(artalk_model* m, int mode) {
     if (!m || (mode != 0 && mode != 1)) return ARTALK_EINVAL;
-    if (mode != m->precision) {   // captured graphs hold the other mode's kernels
-        (void)hipSetDevice(m->device);
-        (void)hipDeviceSynchronize();
-        for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
-        m->graphs.clear();
-        m->precision = mode;
-    }
+    m->precision = mode;   // captured graphs are keyed by mode: switching costs nothing and keeps both sets
     return ARTALK_OK;
 }
 int artalk_set_graphs(artalk_model* m, int enable) {
@@ -1019,7 +1071,9 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
     if (B > m->ws.maxB || C > m->ws.maxC) { if (int rc = reserve(m, B, (int)C)) return rc; }
     Workspace& w = m->ws;
     // chunk list, chunk-index major: chunk (j, b) for all b with n_chunks[b] > j  -> active clips are a prefix
-    std::vector<long> src((size_t)C);
+    artalk_model::Stage* stg = nullptr;
+    if (int rc = next_stage(m, &stg)) return rc;
+    long* src = stg->src;
     std::vector<int> base((size_t)maxch + 1, 0), Bj((size_t)maxch, 0);
     {
         int idx = 0;
@@ -1029,9 +1083,13 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
         }
         base[maxch] = idx;
     }
-    HIPCHK(m, hipMemcpyAsync(w.src_off, src.data(), C * sizeof(long), hipMemcpyHostToDevice, s));
-    if (style_motion_dev && has_style) HIPCHK(m, hipMemcpyAsync(w.has_style, has_style, B, hipMemcpyHostToDevice, s));
-    HIPCHK(m, hipStreamSynchronize(s));   // src/has_style are stack/heap temporaries of this call
+    HIPCHK(m, hipMemcpyAsync(w.src_off, src, C * sizeof(long), hipMemcpyHostToDevice, s));
+    if (style_motion_dev && has_style) {
+        std::memcpy(stg->has, has_style, (size_t)B);
+        HIPCHK(m, hipMemcpyAsync(w.has_style, stg->has, B, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(m, hipEventRecord(stg->done, s));   // pinned slot: no synchronisation, the slot is reused kStageSlots calls later
+    stg->used = true;
     m->stream_B = 0;   // the batch call reuses the workspace that holds the streaming history
     HIPCHK(m, hipMemsetAsync(w.status, 0, 4 * sizeof(int), s));
     m->ev_used = 0; m->dom_events.clear(); m->marks.clear(); m->marks_w2v.clear(); m->prof_stream = s;
@@ -1066,7 +1124,14 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
         m->view = nullptr;
     }
     stage_mark(m, s, PB_OTHER);
-    run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s);
+    bool encode_style = false;
+    if (style_motion_dev && has_style) {
+        for (int b = 0; b < B; ++b) {
+            if (has_style[b] > 2) return fail(m, ARTALK_EINVAL, "has_style entries must be 0, 1 or 2");
+            encode_style |= has_style[b] == 1;
+        }
+    }
+    run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s, encode_style);
     stage_mark(m, s, PB_STYLE);
     if (!overlap) {
         for (int c0 = 0; c0 < C; c0 += w.G) {
@@ -1106,8 +1171,30 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
                                        bits_row, Bn, hipMemcpyDeviceToDevice, s));
     }
     stage_mark(m, s, PB_OTHER);
+    if (int rc = publish_status(m, s)) return rc;
     HIPCHK(m, hipGetLastError());
     if (m->sticky_error) { m->sticky_error = false; return ARTALK_ESTATE; }
+    return ARTALK_OK;
+}
+
+// Style-clip cache support: the style condition of app/models.py:67-73 depends on the style clip only,
+// and the reference's engine keeps ONE style clip across many inference calls (inference.py:41-45,115-118).  This computes the
+// conditions of n clips once; a later artalk_infer / artalk_stream_begin takes such a condition in place of the clip (flag 2).
+int artalk_style_encode(artalk_model* m, const float* style_motion_dev, int n, float* out_cond_dev, void* stream) {
+    if (!m || !style_motion_dev || !out_cond_dev || n <= 0) return ARTALK_EINVAL;
+    if (!m->finalized) return fail(m, ARTALK_ESTATE, "artalk_style_encode before artalk_finalize_weights");
+    (void)hipSetDevice(m->device);
+    if (!stream && !m->own_stream) HIPCHK(m, hipStreamCreate(&m->own_stream));
+    hipStream_t s = stream ? (hipStream_t)stream : m->own_stream;
+    if (m->stream_B > 0) return fail(m, ARTALK_ESTATE, "artalk_style_encode during a streaming session (it shares the workspace)");
+    if (n > m->ws.maxB) { if (int rc = reserve(m, n, std::max(n, m->ws.maxC))) return rc; }
+    Workspace& w = m->ws;
+    HIPCHK(m, hipMemsetAsync(w.has_style, 1, n, s));
+    const int saved = m->profiling; m->profiling = 0;
+    run_style(m, style_motion_dev, n, s, true);
+    m->profiling = saved;
+    HIPCHK(m, hipMemcpyAsync(out_cond_dev, w.style_cond, (size_t)n * kE * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(m, hipGetLastError());
     return ARTALK_OK;
 }
 
@@ -1121,17 +1208,27 @@ int artalk_stream_begin(artalk_model* m, int B, const float* style_motion_dev, c
     if (!stream && !m->own_stream) HIPCHK(m, hipStreamCreate(&m->own_stream));
     hipStream_t s = stream ? (hipStream_t)stream : m->own_stream;
     if (B > m->ws.maxB || B > m->ws.maxC) { if (int rc = reserve(m, B, B)) return rc; }
+    if (int rc = ensure_stage(m, m->ws.maxB, m->ws.maxC)) return rc;
     Workspace& w = m->ws;
     if (style_motion_dev && has_style) {
-        HIPCHK(m, hipMemcpyAsync(w.has_style, has_style, B, hipMemcpyHostToDevice, s));
-        HIPCHK(m, hipStreamSynchronize(s));
+        artalk_model::Stage* stg = nullptr;
+        if (int rc = next_stage(m, &stg)) return rc;
+        std::memcpy(stg->has, has_style, (size_t)B);
+        HIPCHK(m, hipMemcpyAsync(w.has_style, stg->has, B, hipMemcpyHostToDevice, s));
+        HIPCHK(m, hipEventRecord(stg->done, s));
+        stg->used = true;
     }
+    HIPCHK(m, hipMemsetAsync(w.status, 0, 4 * sizeof(int), s));   // the status word covers the whole streaming session
     const int saved = m->profiling; m->profiling = 0;
-    run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s);
+    bool encode_style = false;
+    if (style_motion_dev && has_style)
+        for (int b = 0; b < B; ++b) encode_style |= has_style[b] == 1;
+    run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s, encode_style);
     launch_enc_input_zero(m->vae_mean, m->vae_std, m->enc_pos, w.enc_in, B, s);
     run_reencode(m, B, s);
     m->profiling = saved;
     m->stream_B = B;
+    if (int rc = publish_status(m, s)) return rc;
     HIPCHK(m, hipGetLastError());
     return ARTALK_OK;
 }
@@ -1148,10 +1245,12 @@ int artalk_stream_chunk(artalk_model* m, const float* audio_dev, int64_t chunk_s
     const int B = m->stream_B;
     Workspace& w = m->ws;
     if (B > w.maxB) return fail(m, ARTALK_ESTATE, "workspace was re-reserved since artalk_stream_begin; begin again");
-    std::vector<long> src((size_t)B);
-    for (int b = 0; b < B; ++b) src[b] = (long)b * chunk_stride;
-    HIPCHK(m, hipMemcpyAsync(w.src_off, src.data(), B * sizeof(long), hipMemcpyHostToDevice, s));
-    HIPCHK(m, hipStreamSynchronize(s));
+    artalk_model::Stage* stg = nullptr;
+    if (int rc = next_stage(m, &stg)) return rc;
+    for (int b = 0; b < B; ++b) stg->src[b] = (long)b * chunk_stride;
+    HIPCHK(m, hipMemcpyAsync(w.src_off, stg->src, B * sizeof(long), hipMemcpyHostToDevice, s));
+    HIPCHK(m, hipEventRecord(stg->done, s));
+    stg->used = true;
     const int saved = m->profiling; m->profiling = 0;
     for (int c0 = 0; c0 < B; c0 += w.G) run_wav2vec(m, audio_dev, c0, std::min(w.G, B - c0), nullptr, s);
     linear(m, w.silu_cond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, B * kNTok, m->ada_n, kCond, ACT_NONE, nullptr, s,
@@ -1164,22 +1263,34 @@ int artalk_stream_chunk(artalk_model* m, const float* audio_dev, int64_t chunk_s
     m->profiling = saved;
     const size_t mrow = (size_t)100 * m->cfg.motion_dim * 4;
     HIPCHK(m, hipMemcpy2DAsync(out_motion_dev, (size_t)out_stride * 4, w.motion_chunk, mrow, mrow, B, hipMemcpyDeviceToDevice, s));
+    if (int rc = publish_status(m, s)) return rc;
     HIPCHK(m, hipGetLastError());
     return ARTALK_OK;
 }
 
-// Numerical health of the calls since the last artalk_infer started (synchronises `stream`): bit 0 = a logit was NaN/Inf (the
-// pairwise argmax would have turned it into a 0 bit), bit 1 = a re-encoder output was NaN/Inf.  Non-zero in f16x3 mode means an
-// activation left fp16's range: redo the call in f32 mode.
+// Numerical health of the work enqueued since the last artalk_infer / artalk_stream_begin started.  Every call ends with an
+// asynchronous copy of the device status word into pinned host memory; artalk_get_status waits for that copy (the only
+// synchronisation on this boundary, and only if the caller asks), artalk_poll_status never blocks (ARTALK_EBUSY while the call is
+// still running).  Bits: 0 = a logit was NaN/Inf (the pairwise argmax would have turned it into a 0 bit), 1 = a re-encoder
+// output was NaN/Inf, 2 = a FLAME code was NaN/Inf, 3 = an activation left the range of the P8 split format at its producer.
+// Non-zero in f16x3 mode means an activation left fp16's range: redo the call in f32 mode.
 int artalk_get_status(artalk_model* m, int* flags, void* stream) {
+    (void)stream;      // kept for ABI compatibility: the wait is on the library's own event, not on a stream
     if (!m || !flags) return ARTALK_EINVAL;
-    if (!m->ws.status) { *flags = 0; return ARTALK_OK; }
+    if (!m->status_pending) { *flags = 0; return ARTALK_OK; }
     (void)hipSetDevice(m->device);
-    hipStream_t s = stream ? (hipStream_t)stream : m->own_stream;
-    int h = 0;
-    HIPCHK(m, hipMemcpyAsync(&h, m->ws.status, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(m, hipStreamSynchronize(s));
-    *flags = h;
+    HIPCHK(m, hipEventSynchronize(m->status_ev));
+    *flags = m->h_status[0];
+    return ARTALK_OK;
+}
+int artalk_poll_status(artalk_model* m, int* flags) {
+    if (!m || !flags) return ARTALK_EINVAL;
+    if (!m->status_pending) { *flags = 0; return ARTALK_OK; }
+    (void)hipSetDevice(m->device);
+    const hipError_t e = hipEventQuery(m->status_ev);
+    if (e == hipErrorNotReady) return ARTALK_EBUSY;
+    if (e != hipSuccess) { m->err = std::string("hipEventQuery: ") + hipGetErrorString(e); return ARTALK_EHIP; }
+    *flags = m->h_status[0];
     return ARTALK_OK;
 }
 
@@ -1363,7 +1474,7 @@ int artalk_op_pool_silu(const float* X, int C, int T, int D, float* Y, void* str
 
 int artalk_op_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fdec, float* msfeat, int B, void* stream) {
     if (!enc_out || !hist_bits || !prev_fdec || !msfeat || B <= 0) return ARTALK_EINVAL;
-    init_ms_tables();
+    if (init_ms_tables() != 0) return ARTALK_EHIP;
     launch_bsq_history(enc_out, hist_bits, prev_fdec, msfeat, B, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }

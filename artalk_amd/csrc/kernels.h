@@ -126,9 +126,10 @@ void launch_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fd
                         int* status = nullptr);    // status |= 2 if an encoder output is not finite
 // style: X[b*50+t, 0:128] = (m - mean)/std (cols >= 106 zero)
 void launch_style_input(const float* motion, const float* mean, const float* stdv, float* X, int B, hipStream_t s);
-// style_cond[b] = has_style[b] ? 1.1*(Ws*mean_t(feat[b]) + bs) - 0.1*null : null
+// style_cond[b] = has_style[b] == 1 ? 1.1*(Ws*mean_t(feat[b]) + bs) - 0.1*null : has_style[b] == 2 ? cached[b*cached_stride ..] : null
 void launch_style_finish(const float* feat /*[B*50,128]*/, const float* Ws, const float* bs, const float* null_cond,
-                         const uint8_t* has_style, float* style_cond, int B, hipStream_t s);
+                         const uint8_t* has_style, float* style_cond, int B, hipStream_t s, const float* cached = nullptr,
+                         long cached_stride = 0);
 // y[m, :] = x[m, :] + v[:]   (broadcast add of one row; used for the style PE quirk)
 void launch_add_row(float* X, const float* v, int M, int D, hipStream_t s);
 // Savitzky-Golay post filter of reference inference.py:89-95 on device: in [T,106] -> out [T,106]
@@ -143,6 +144,6 @@ void launch_flame_pose(const float* pose, float* rot, float* feat, int T, int ld
 void launch_flame_joints(const float* vs, const float* jreg, float* J, int T, int V, hipStream_t s);
 void launch_flame_skin(const float* vposed, const float* rot, const float* J, const int* parents, const float* weights, float* out,
                        int T, int V, float scale, hipStream_t s);
-void init_ms_tables();   // uploads the (tiny) interpolation tables to __constant__ memory; idempotent
+int init_ms_tables();    // uploads the (tiny) interpolation tables to the CURRENT device's __constant__ memory, once per device; 0 = ok
 
 }  // namespace artalk

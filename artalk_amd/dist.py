@@ -4,14 +4,22 @@ Clips share nothing but read-only weights and chunks inside a clip are sequentia
 one process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm), weights replicated
 (2 GB of 288 GB), no data-path collective.  The only exchange is the optional collection of results: one
 all-gather of the padded FLAME codes and one of the lengths.  The same code runs on the gloo backend with
-CPU tensors (tests/test_dist_gloo.py).
+CPU tensors (tests/test_dist_gloo.py) and is what ``bench.py`` runs for N > 1.
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+import math
+import os
+import socket
+from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+
+
+def seq_length(n_samples: int) -> int:
+    """Frames of a clip, the float formula of app/models.py:66 (== BitwiseARModel.seq_length)."""
+    return math.ceil(n_samples / 16000 * 25.0)
 
 
 def shard_range(n_items: int, rank: int, world_size: int) -> range:
@@ -21,11 +29,27 @@ def shard_range(n_items: int, rank: int, world_size: int) -> range:
     return range(lo, hi)
 
 
-def gather_clips(local: Sequence[torch.Tensor], max_frames: int, group=None) -> List[torch.Tensor]:
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def init_single_process_group(backend: str = "nccl", device: Optional[torch.device] = None):
+    """A world-size-1 process group (used by ``bench.py --force-collective`` and the GPU test of the RCCL path: the same
+    init + all-gather code as N > 1, on one GPU).  Rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
+    kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+    dist.init_process_group(backend, rank=0, world_size=1, **kw)
+
+
+def gather_clips(local: Sequence[torch.Tensor], max_frames: int, group=None, force_collective: bool = False) -> List[torch.Tensor]:
     """All-gather per-clip results ``(T_i, D)`` of every rank; returns the clips of all ranks in rank order on
-    every rank.  Every rank must pass the same number of clips (pad the shard with empty ``(0, D)`` tensors)."""
+    every rank.  Every rank must pass the same number of clips (pad the shard with empty ``(0, D)`` tensors).
+    With one rank nothing is exchanged unless ``force_collective`` (then the collective runs over the 1-rank group)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return list(local)
     n = len(local)
     D = local[0].shape[1]
@@ -33,6 +57,7 @@ def gather_clips(local: Sequence[torch.Tensor], max_frames: int, group=None) -> 
     buf = torch.zeros(n, max_frames, D, dtype=local[0].dtype, device=dev)
     lens = torch.zeros(n, dtype=torch.int64, device=dev)
     for i, t in enumerate(local):
+        assert t.shape[0] <= max_frames, f"clip of {t.shape[0]} frames does not fit the gather buffer ({max_frames})"
         buf[i, : t.shape[0]] = t
         lens[i] = t.shape[0]
     all_buf = torch.empty(world * n, max_frames, D, dtype=buf.dtype, device=dev)
@@ -43,9 +68,12 @@ def gather_clips(local: Sequence[torch.Tensor], max_frames: int, group=None) -> 
     return [all_buf[i, : all_len[i]] for i in range(world * n)]
 
 
-def run_sharded(infer_fn, audios: Sequence[torch.Tensor], styles=None, gather: bool = True, group=None):
+def run_sharded(infer_fn, audios: Sequence[torch.Tensor], styles=None, gather: bool = True, group=None,
+                max_frames: Optional[int] = None, force_collective: bool = False):
     """Shard ``audios`` over the ranks, run ``infer_fn(list_of_audio, list_of_style)`` on the local shard and
-    (optionally) all-gather.  Result order equals input order; shards are padded to equal size with empties."""
+    (optionally) all-gather.  Result order equals input order; shards are padded to equal size with empties.
+    ``audios`` only needs ``len()`` and indexing (a lazy sequence may build just the local clips); pass ``max_frames``
+    (frames of the longest clip of ALL ranks) in that case, otherwise it is derived from every clip's length."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = len(audios)
@@ -53,14 +81,20 @@ def run_sharded(infer_fn, audios: Sequence[torch.Tensor], styles=None, gather: b
     loc_a = [audios[i] for i in mine]
     loc_s = [styles[i] for i in mine] if styles is not None else None
     out = infer_fn(loc_a, loc_s) if loc_a else []
-    if not gather or world == 1:
+    if not gather or (world == 1 and not force_collective):
         return out
     per = max(len(shard_range(n, r, world)) for r in range(world))
     D = out[0].shape[1] if out else 106
-    dev = out[0].device if out else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+    if out:
+        dev = out[0].device
+    elif dist.get_backend(group) == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = torch.device("cpu")
     padded = list(out) + [torch.zeros(0, D, device=dev)] * (per - len(out))
-    max_frames = max(-(-int(a.shape[0]) * 25 // 16000) for a in audios)   # ceil(N/640)
-    allc = gather_clips(padded, max_frames, group)
+    if max_frames is None:
+        max_frames = max(seq_length(int(audios[i].shape[-1])) for i in range(n))
+    allc = gather_clips(padded, max_frames, group, force_collective)
     res = []
     for r in range(world):
         k = len(shard_range(n, r, world))

@@ -21,11 +21,13 @@ from .model import BitwiseARModel
 
 class ARTAvatarInferEngine:
     def __init__(self, load_gaga=False, fix_pose=False, clip_length=750, device="cuda",
-                 ckpt_path="./assets/ARTalk_wav2vec.pt", config_path=None, state_dict=None, config=None):
+                 ckpt_path="./assets/ARTalk_wav2vec.pt", config_path=None, state_dict=None, config=None, model=None):
         self.device = device
         self.fix_pose = fix_pose
         self.clip_length = clip_length
         audio_encoder = "wav2vec"                                           # inference.py:23
+        if model is not None:          # an already loaded BitwiseARModel (several engines may share the 2 GB of weights)
+            state_dict, config = {}, model.cfg
         if state_dict is None:
             # FileNotFoundError for a missing checkpoint, like torch.load at inference.py:24
             state_dict = torch.load(ckpt_path, map_location="cpu", weights_only=True)
@@ -36,8 +38,11 @@ class ARTAvatarInferEngine:
                 configs = ARTalkConfig.full().reference_dict()            # == assets/config.json
             configs["AR_CONFIG"]["AUDIO_ENCODER"] = audio_encoder
             config = ARTalkConfig.from_reference_dict(configs)
-        self.ARTalk = BitwiseARModel(config).eval().to(device)
-        self.ARTalk.load_state_dict(state_dict, strict=True)
+        if model is not None:
+            self.ARTalk = model
+        else:
+            self.ARTalk = BitwiseARModel(config).eval().to(device)
+            self.ARTalk.load_state_dict(state_dict, strict=True)
         # renderer-side attributes of the reference object; filled by whoever owns the (out of scope) renderers
         self.flame_model = None
         self.mesh_renderer = None
@@ -74,8 +79,9 @@ class ARTAvatarInferEngine:
         pred_motions[..., 104:] *= 0.0
         return pred_motions
 
-    def smooth_motion_savgol_device(self, motion_codes):
-        """``smooth_motion_savgol`` (inference.py:89-95) without the host round trip: same filter on the GPU."""
+    def smooth_motion_savgol(self, motion_codes):
+        """``smooth_motion_savgol`` (inference.py:89-95) without the host round trip: Savitzky-Golay (5, 2) on all dims,
+        (9, 3) on dims 100:103 of the unsmoothed signal, scipy's mode='interp' edges, as a device kernel (artalk_savgol)."""
         T = motion_codes.shape[0]
         if T < 9:
             # scipy raises for mode='interp' when window_length (9 for the pose dims) exceeds the signal length
@@ -88,14 +94,7 @@ class ARTAvatarInferEngine:
             raise RuntimeError("artalk_savgol failed: " + self.ARTalk._err())
         return out
 
-    @staticmethod
-    def smooth_motion_savgol(motion_codes):
-        """The reference's own host implementation (scipy), kept for callers that want it bit for bit."""
-        from scipy.signal import savgol_filter
-        motion_np = motion_codes.clone().detach().cpu().numpy()
-        motion_np_smoothed = savgol_filter(motion_np, window_length=5, polyorder=2, axis=0)
-        motion_np_smoothed[..., 100:103] = savgol_filter(motion_np[..., 100:103], window_length=9, polyorder=3, axis=0)
-        return torch.tensor(motion_np_smoothed).type_as(motion_codes)
+    smooth_motion_savgol_device = smooth_motion_savgol
 
     def rendering(self, audio, pred_motions, shape_id="mesh", shape_code=None, save_name="ARTAvatar.mp4"):
         """Downstream of the boundary (inference.py:59-87).  Produces the vertices the reference's mesh branch would

@@ -59,8 +59,13 @@ class BitwiseARModel:
         self._h = None
         self._loaded = False
         self._reserved = (0, 0)
-        self.check_finite = True   # f16x3 mode: verify the result is finite (one small reduction + sync per call)
+        # f16x3 mode: read the status word the library publishes at the end of every call (one event wait per call; the library
+        # itself never synchronises).  False = fully asynchronous calls, the caller polls ``status(wait=False)`` when it likes.
+        self.check_finite = True
         self._precision = "f16x3"   # default GEMM arithmetic (set_precision); applied when the weights are loaded
+        self._latched_f32 = False   # an f16x3 call left fp16's range once: the model stays in f32 mode from then on
+        self.style_cache_size = 64  # style conditions kept by style clip (set 0 to disable)
+        self._style_cache = {}      # key -> (style tensor kept alive, (768,) condition on the device)
         self._overlap = False       # overlapped wav2vec2 / AR schedule (set_overlap), opt-in
         self._stream = None      # dedicated HIP stream (hipGraph capture is not allowed on the legacy default stream)
         self.last_aux = {}
@@ -106,6 +111,7 @@ class BitwiseARModel:
         if self._h is not None and self._loaded:      # reloading: derived layouts/packed copies belong to the old weights
             L.artalk_destroy(self._h)
             self._h, self._loaded, self._stream = None, False, None
+        self._style_cache = {}
         if self._h is None:
             h = C.c_void_p()
             cs = capi.config_struct(self.cfg)
@@ -146,11 +152,31 @@ class BitwiseARModel:
             raise RuntimeError("artalk_reserve failed: " + self._err())
         self._reserved = (int(max_batch), int(max_total_chunks))
 
-    def _status(self) -> int:
-        """Health flags of the last call (artalk_get_status): non-zero = a NaN/Inf reached a decision."""
+    def status(self, wait: bool = True) -> Optional[int]:
+        """Health flags of the last call (bit 0 logit, 1 re-encoder output, 2 FLAME code not finite, 3 an activation left the
+        range of the f16x3 operand format).  ``wait=True`` waits for the call to finish (artalk_get_status); ``wait=False``
+        never blocks and returns None while the call is still running (artalk_poll_status)."""
         f = C.c_int(0)
-        capi.lib().artalk_get_status(self._h, C.byref(f), C.c_void_p(self._stream.cuda_stream) if self._stream is not None else None)
+        if wait:
+            rc = capi.lib().artalk_get_status(self._h, C.byref(f), None)
+        else:
+            rc = capi.lib().artalk_poll_status(self._h, C.byref(f))
+            if rc == capi.EBUSY:
+                return None
+        if rc != capi.OK:
+            raise RuntimeError("artalk status query failed: " + self._err())
         return int(f.value)
+
+    _status = status
+
+    def _trip_to_f32(self, what: str):
+        """An activation left fp16's range in f16x3 mode: switch to exact-f32 GEMMs for good (a checkpoint that trips once will
+        trip again; retrying f16x3 on every call would cost both runs every time)."""
+        import warnings
+        warnings.warn(f"artalk_amd: non-finite result in f16x3 mode ({what}); re-running in f32 mode and staying there "
+                      "(set_precision('f16x3') switches back)")
+        self.set_precision("f32")
+        self._latched_f32 = True
 
     def workspace_bytes(self):
         return int(capi.lib().artalk_workspace_bytes(self._h))
@@ -170,6 +196,7 @@ class BitwiseARModel:
         if code not in (0, 1):
             raise ValueError("precision mode must be 'f32' or 'f16x3'")
         self._precision = "f16x3" if code == 1 else "f32"
+        self._latched_f32 = False
         if self._h is not None and self._loaded:
             rc = capi.lib().artalk_set_precision(self._h, int(code))
             if rc != capi.OK:
@@ -195,26 +222,73 @@ class BitwiseARModel:
                 "dom_launches", "dom_ms", "dom_flop"]
         return dict(zip(keys, list(out)))
 
+    # ------------------------------------------------------------------ style-clip cache
+    def _style_rows(self, style_motions, order, B):
+        """(style_t [B,50,106] or None, has [B] or None) for artalk_infer / artalk_stream_begin.  A style clip seen before is
+        passed as its cached 768-float condition (flag 2: the style encoder is skipped for it); new clips go in as clips (flag 1)
+        and, when the cache is on, their condition is computed first by one artalk_style_encode call and remembered."""
+        if style_motions is None or not any(s is not None for s in style_motions):
+            return None, None
+        dev = self._device
+        L, D = self.cfg.style_len, self.cfg.motion_dim
+        style_t = torch.zeros(B, L, D, dtype=torch.float32, device=dev)
+        has = (C.c_uint8 * B)()
+        keys = {}
+        for pos, i in enumerate(order):
+            s = style_motions[i]
+            if s is None:
+                continue
+            assert tuple(s.shape) == (L, D), f"Invalid style_motion shape: {tuple(s.shape)}."
+            if self.style_cache_size > 0:
+                keys[pos] = (s.data_ptr(), s._version, str(s.device), self._precision)
+            else:
+                style_t[pos] = s.to(device=dev, dtype=torch.float32)
+                has[pos] = 1
+        if keys:
+            new = {}
+            for pos, k in keys.items():
+                if k not in self._style_cache and k not in new:
+                    new[k] = style_motions[order[pos]]
+            if new:
+                clips = torch.stack([v.to(device=dev, dtype=torch.float32) for v in new.values()])
+                cond = torch.empty(len(new), self.cfg.embed_dim, dtype=torch.float32, device=dev)
+                self._stream.wait_stream(torch.cuda.current_stream())
+                rc = capi.lib().artalk_style_encode(self._h, capi.ptr(clips), len(new), capi.ptr(cond), C.c_void_p(self._stream.cuda_stream))
+                if rc != capi.OK:
+                    raise RuntimeError("artalk_style_encode failed: " + self._err())
+                torch.cuda.current_stream().wait_stream(self._stream)
+                clips.record_stream(self._stream)
+                cond.record_stream(self._stream)
+                for j, (k, v) in enumerate(new.items()):
+                    self._style_cache[k] = (v, cond[j])       # v is kept alive so that its data_ptr cannot be recycled
+                while len(self._style_cache) > self.style_cache_size:
+                    self._style_cache.pop(next(iter(self._style_cache)))
+            flat = style_t.view(B, L * D)
+            for pos, k in keys.items():
+                hit = self._style_cache.get(k) or (None, None)
+                if hit[1] is None:          # evicted within this very call (more new clips than the cache holds)
+                    style_t[pos] = style_motions[order[pos]].to(device=dev, dtype=torch.float32)
+                    has[pos] = 1
+                else:
+                    flat[pos, :self.cfg.embed_dim] = hit[1]
+                    has[pos] = 2
+        return style_t, has
+
     # ------------------------------------------------------------------ streaming (chunk-at-a-time, persistent history)
     @torch.no_grad()
     def stream_begin(self, n_streams: int, style_motions: Optional[Sequence[Optional[torch.Tensor]]] = None):
-        """Open ``n_streams`` parallel streams: style condition + initial history (app/models.py:67-73,86-89)."""
+        """Open ``n_streams`` parallel streams: style condition + initial history (app/models.py:67-73,86-89).  The session
+        lasts until ``stream_end()``, the next ``stream_begin`` or any ``inference*`` call (they share the workspace)."""
         if not self._loaded:
             raise RuntimeError("load_state_dict must be called before inference")
         dev = self._device
         with torch.cuda.device(dev):
-            style_t, has = None, None
-            if style_motions is not None and any(s is not None for s in style_motions):
-                style_t = torch.zeros(n_streams, self.cfg.style_len, self.cfg.motion_dim, dtype=torch.float32, device=dev)
-                has = (C.c_uint8 * n_streams)()
-                for i, s in enumerate(style_motions):
-                    if s is not None:
-                        assert tuple(s.shape) == (self.cfg.style_len, self.cfg.motion_dim), f"Invalid style_motion shape: {tuple(s.shape)}."
-                        style_t[i] = s.to(device=dev, dtype=torch.float32)
-                        has[i] = 1
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=dev)
             caller = torch.cuda.current_stream()
+            self._stream.wait_stream(caller)
+            self._n_streams = 0        # artalk_style_encode refuses to run inside a session
+            style_t, has = self._style_rows(style_motions, list(range(n_streams)), n_streams)
             self._stream.wait_stream(caller)
             rc = capi.lib().artalk_stream_begin(self._h, int(n_streams), capi.ptr(style_t),
                                                 C.cast(has, C.c_void_p) if has is not None else None, C.c_void_p(self._stream.cuda_stream))
@@ -224,11 +298,22 @@ class BitwiseARModel:
         if rc != capi.OK:
             raise RuntimeError("artalk_stream_begin failed: " + self._err())
         self._n_streams = int(n_streams)
+        self._stream_style = style_motions
+        self._stream_fed = [0] * self._n_streams      # samples fed per stream (for end-of-clip bookkeeping)
 
     @torch.no_grad()
-    def stream_chunk(self, audio_chunks: torch.Tensor) -> torch.Tensor:
-        """Next 4 seconds of every stream: ``(n_streams, 64000)`` float32 (zero padded at a clip's end) -> ``(n_streams, 100, 106)``."""
+    def stream_chunk(self, audio_chunks: torch.Tensor, n_valid: Optional[Sequence[int]] = None):
+        """Next 4 seconds of every stream: ``(n_streams, 64000)`` float32 -> ``(n_streams, 100, 106)``.
+
+        End of a clip: the caller zero-pads the last chunk, exactly as the reference pads the whole clip to a multiple of 4 s
+        (app/models.py:78-85; the per-chunk normalisation sees the zeros, as it does there), and passes ``n_valid`` = the
+        number of real samples of each stream in this chunk (default: all 64000).  The call then also returns the number of
+        valid frames per stream, ``ceil(total_samples * 25 / 16000) - 100 * chunks_before`` clipped to [0, 100] - the rows the
+        reference keeps after its final truncation (app/models.py:115).  A stream whose clip has ended is fed zeros
+        (``n_valid = 0``) until the session ends; its rows are ignored."""
         B = getattr(self, "_n_streams", 0)
+        if B <= 0:
+            raise RuntimeError("stream_chunk before stream_begin")
         assert audio_chunks.shape == (B, self.cfg.samples_per_chunk), f"expected ({B}, {self.cfg.samples_per_chunk}) samples"
         dev = self._device
         with torch.cuda.device(dev):
@@ -243,7 +328,28 @@ class BitwiseARModel:
             out.record_stream(self._stream)
         if rc != capi.OK:
             raise RuntimeError("artalk_stream_chunk failed: " + self._err())
-        return out
+        if self._precision == "f16x3" and self.check_finite and self.status() != 0:
+            # the history of the session already contains the damaged chunk: the session cannot be repaired in place
+            self._n_streams = 0
+            self._trip_to_f32("streaming chunk")
+            raise RuntimeError("artalk_amd: an activation left fp16's range during a streaming chunk; the model is now in f32 "
+                               "mode - begin the streaming session again")
+        if n_valid is None:
+            return out
+        frames = []
+        for b in range(B):
+            before = self._stream_fed[b]
+            self._stream_fed[b] = before + int(n_valid[b])
+            if int(n_valid[b]) <= 0:
+                frames.append(0)
+                continue
+            total = self.seq_length(self._stream_fed[b])
+            frames.append(max(0, min(100, total - 100 * (before // self.cfg.samples_per_chunk))))
+        return out, frames
+
+    def stream_end(self):
+        """Close the streaming session (history is dropped)."""
+        self._n_streams = 0
 
     # ------------------------------------------------------------------ geometry of app/models.py:66,78-80
     def seq_length(self, n_samples: int) -> int:
@@ -281,6 +387,10 @@ class BitwiseARModel:
         if B == 0:
             return []
         dev = self._device
+        self._n_streams = 0          # a batch call ends a streaming session (shared workspace)
+        packed = isinstance(audios, torch.Tensor)      # (B, N): equal-length clips in one tensor -> one H2D copy, no per-clip loop
+        if packed and (audios.dim() != 2 or audios.shape[1] == 0):
+            raise ValueError("a packed batch must be a (B, N) float tensor of 16 kHz samples")
         n_samples = [int(a.shape[-1]) for a in audios]
         for a in audios:
             if a.dim() != 1 or a.shape[0] == 0:
@@ -291,19 +401,20 @@ class BitwiseARModel:
         maxch, total = nch[order[0]], sum(nch)
         spc = self.cfg.samples_per_chunk
         with torch.cuda.device(dev):
-            audio_pad = torch.zeros(B, maxch * spc, dtype=torch.float32, device=dev)   # zero padding of app/models.py:81-85
-            for pos, i in enumerate(order):
-                audio_pad[pos, :n_samples[i]] = audios[i].to(device=dev, dtype=torch.float32, non_blocking=True)
-            style_t, has = None, None
-            if style_motions is not None and any(s is not None for s in style_motions):
-                style_t = torch.zeros(B, self.cfg.style_len, self.cfg.motion_dim, dtype=torch.float32, device=dev)
-                has = (C.c_uint8 * B)()
-                for pos, i in enumerate(order):
-                    s = style_motions[i]
-                    if s is not None:
-                        assert tuple(s.shape) == (self.cfg.style_len, self.cfg.motion_dim), f"Invalid style_motion shape: {tuple(s.shape)}."
-                        style_t[pos] = s.to(device=dev, dtype=torch.float32)
-                        has[pos] = 1
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=dev)
+            caller = torch.cuda.current_stream()
+            if packed and n_samples[0] == maxch * spc:
+                audio_pad = audios.to(device=dev, dtype=torch.float32, non_blocking=True)      # already whole chunks
+            else:
+                audio_pad = torch.zeros(B, maxch * spc, dtype=torch.float32, device=dev)   # zero padding of app/models.py:81-85
+                if packed:
+                    audio_pad[:, :n_samples[0]] = audios.to(device=dev, dtype=torch.float32, non_blocking=True)
+                else:
+                    for pos, i in enumerate(order):      # host clips (pinned or not) go straight into their row: one H2D copy each
+                        audio_pad[pos, :n_samples[i]].copy_(audios[i], non_blocking=True)
+            self._stream.wait_stream(caller)
+            style_t, has = self._style_rows(style_motions, order, B)
             out = torch.zeros(B, maxch * 100, self.cfg.motion_dim, dtype=torch.float32, device=dev)   # zeros: rows past a clip's last chunk
             bits = hist = w2v = None
             if return_aux:
@@ -311,9 +422,6 @@ class BitwiseARModel:
                 hist = torch.zeros(B, maxch + 1, 181, 32, dtype=torch.uint8, device=dev)
                 w2v = torch.zeros(total, 199, self.cfg.cond_dim, dtype=torch.float32, device=dev)
             nch_sorted = (C.c_int64 * B)(*[nch[i] for i in order])
-            if self._stream is None:
-                self._stream = torch.cuda.Stream(device=dev)
-            caller = torch.cuda.current_stream()
             self._stream.wait_stream(caller)
             rc = L.artalk_infer(self._h, capi.ptr(audio_pad), audio_pad.stride(0), nch_sorted, B, capi.ptr(style_t),
                                 C.cast(has, C.c_void_p) if has is not None else None, capi.ptr(out), out.stride(0),
@@ -324,15 +432,11 @@ class BitwiseARModel:
                     t.record_stream(self._stream)
             if rc != capi.OK:
                 raise RuntimeError("artalk_infer failed ({}): {}".format(rc, self._err()))
-            if self._precision == "f16x3" and self.check_finite and self._status() != 0:
-                # an activation left fp16's range: redo this call with exact fp32 MFMA GEMMs (never silently return NaNs)
-                import warnings
-                warnings.warn("artalk_amd: non-finite result in f16x3 mode, re-running this call in f32 mode")
-                self.set_precision("f32")
-                try:
-                    return self.inference_batch(audios, style_motions, return_aux)
-                finally:
-                    self.set_precision("f16x3")
+            if self._precision == "f16x3" and self.check_finite and self.status() != 0:
+                # an activation left fp16's range: redo this call with exact fp32 MFMA GEMMs (never silently return NaNs) and
+                # stay in f32 mode - a checkpoint that trips once trips again, and both runs per call would cost 3.4x
+                self._trip_to_f32("inference_batch")
+                return self.inference_batch(audios, style_motions, return_aux)
             results: List[Optional[torch.Tensor]] = [None] * B
             for pos, i in enumerate(order):
                 results[i] = out[pos, :seq[i]]                               # truncate, app/models.py:115

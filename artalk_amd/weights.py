@@ -132,6 +132,20 @@ def manifest(cfg: ARTalkConfig):
     return m
 
 
+_STATS = None
+
+
+def motion_stats():
+    """``{"motion_mean": [106], "motion_std": [106]}``: the reference's ALLTALKEMICA table (assets/motion_stats.json)."""
+    global _STATS
+    if _STATS is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "motion_stats.json")) as f:
+            _STATS = json.load(f)
+    return _STATS
+
+
 def n_params(cfg: ARTalkConfig):
     return sum(int(np.prod(s)) for s, _, init in manifest(cfg).values() if not init[0].startswith(("buf", "stat")))
 
@@ -164,11 +178,11 @@ def _generate(name, shape, dtype, init, cfg, seed, done):
         a = np.float32(0.1) * (g.random(n, dtype=np.float32) * np.float32(2.0) - np.float32(1.0))
     elif kind == "scale_mul":  # app/transformer.py:54 inits log(4); perturbed per head
         a = np.float32(math.log(4.0)) + np.float32(0.2) * (g.random(n, dtype=np.float32) * np.float32(2.0) - np.float32(1.0))
-    elif kind == "stat_mean":  # stands in for ALLTALKEMICA_MEAN (data_stats.py); dims 100:103 are 0 there too
-        a = np.float32(0.3) * g.standard_normal(n, dtype=np.float32)
-        a[100:103] = 0.0
-    elif kind == "stat_std":
-        a = np.float32(0.05) + np.float32(0.95) * g.random(n, dtype=np.float32)
+    elif kind in ("stat_mean", "stat_std"):
+        # the reference's own ALLTALKEMICA statistics (app/modules/data_stats.py:1-32; persistent buffers of a checkpoint,
+        # bitwise_vae.py:24-25, style_encoder.py:12-13), shipped as data: artalk_amd/assets/motion_stats.json
+        a = np.asarray(motion_stats()["motion_mean" if kind == "stat_mean" else "motion_std"], dtype=np.float32)
+        assert a.shape == (n,), "motion statistics are defined for MOTION_DIM = 106 only"
     elif kind == "wn_g":       # torch weight_norm(dim=2) initialises g = ||v|| over dims (0,1); perturbed
         v = done[init[1]].astype(np.float64)
         nrm = np.sqrt((v * v).sum(axis=(0, 1), keepdims=True)).astype(np.float32)

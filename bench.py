@@ -1,29 +1,40 @@
 #!/usr/bin/env python
 """Headline benchmark: motion frames/s of the audio->motion path at batch 32 x 10 s clips per GPU (BASELINE.json).
 
-One "step" = one pass of the whole hot path (wav2vec2 -> 5-scale AR decode with hipGraph replay -> VAE decode ->
-re-encode) over one batch of 32 synthetic 10-second 16 kHz clips that are already resident in HBM.  N > 1 is
-launched by ``python -m torch.distributed.run`` (one rank per GPU): every rank takes its own 32 clips (weak scaling,
-clips are independent) and the step ends with the RCCL all-gather that collects the FLAME codes of all ranks.
+One "step" = one pass of the whole hot path over one batch of 32 synthetic 10-second 16 kHz clips, measured as SURVEY.md
+section 8(d) defines the metric: H2D of the audio (20 MB from pinned host memory) -> wav2vec2 -> 5-scale AR decode with hipGraph
+replay -> VAE decode -> re-encode -> D2H of the FLAME codes (3.4 MB into pinned host memory).  Weight load and graph capture are
+outside (warmup).  ``--resident`` keeps the audio in HBM and leaves the codes there (the kernel-only number, reported as
+``resident`` in the default run as well).
 
-Prints ONE JSON line (rank 0).  Besides the contract keys it carries ``roofline`` (the dominant kernel: the 128x128-tile
-fp32 MFMA GEMM, timed with HIP events around every eager launch of it inside the timed region) and ``cpu_baseline``
-(the CPU oracle, a restatement pinned bit-exact to the reference, timed on the host cores for a bounded sample).
+``python bench.py --gpus N`` is ONE command for any N: for N > 1 the parent - before it touches the GPU - starts
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...`` as a child
+process and relays rank 0's JSON line and the return code (the driver may also launch it under torchrun itself: RANK /
+WORLD_SIZE in the environment mean "I am a rank").  Every rank takes its own 32 clips (weak scaling, clips are independent,
+``artalk_amd.dist.run_sharded``) and the step ends with the RCCL all-gather that collects the FLAME codes of all ranks.
+``--force-collective`` runs that same init + all-gather code at N = 1.
+
+Prints ONE JSON line (rank 0).  Besides the contract keys it carries ``roofline`` (the dominant kernel, timed with HIP events
+around every eager launch of it inside the timed region) and ``cpu_baseline`` (the CPU oracle, a restatement pinned bit-exact
+to the reference, timed on the host cores for a bounded sample).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything initialises HSA: the host driver only supports dmabuf IPC
 
 GFLOP_PER_FRAME = 2.159          # algorithmic work with KV cache, BASELINE.md section 3
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
+PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"      # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
 MODES = {
-    # precision -> (dtype string, dominant kernel symbol prefix in profiles/*pmc*.json, description, peak TF/s of ALGORITHMIC flops, note)
+    # precision -> (dtype string, dominant kernel symbol prefix in the PMC file, description, peak TF/s of ALGORITHMIC flops, note)
     "f32": ("f32", "gemm_f32_kernel<128, 128, 2, 2, 16, 0, 0>",
             "gemm_f32_kernel<128,128,2,2,16,0,0> (v_mfma_f32_32x32x2_f32): every launch of it (wav2vec2 conv/encoder GEMMs, AdaLN table)",
             PEAK_F32_MFMA_TFLOPS, "fp32 MFMA peak"),
@@ -31,6 +42,7 @@ MODES = {
               "gemm_p8_2wgp_kernel<0> (128x128 tiles, two persistent workgroups per CU, LDS-DMA staged, deferred epilogue, v_mfma_f32_32x32x16_f16 x3 per k-block): every launch of it (the wav2vec2 encoder GEMMs)",
               PEAK_F16_MFMA_TFLOPS / 3.0, "dense fp16 MFMA peak 2500 TF/s / 3 MFMA products per algorithmic product"),
 }
+GOLDEN_SET = os.path.join(REPO, "tests", "golden", "full_cfg2_synth8.npz")    # reference outputs for seeds 0..7 (even seeds unstyled)
 
 
 def log(msg):
@@ -61,7 +73,17 @@ def host_cores():
     return min(n, 32)
 
 
-def main():
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -74,28 +96,61 @@ def main():
     ap.add_argument("--branches", type=int, default=0, help="concurrent clip groups of the AR body (0 = auto)")
     ap.add_argument("--splitk", default="0,0", help="tuning: split-K tile threshold,target workgroups (0 = keep)")
     ap.add_argument("--overlap", action="store_true", help="overlapped schedule: wav2vec2 of chunk index j+1 beside the AR/VAE body of j")
+    ap.add_argument("--resident", action="store_true", help="audio already in HBM, codes left in HBM (no PCIe copies in the step)")
+    ap.add_argument("--force-collective", action="store_true", help="N = 1: still create the RCCL process group and run the all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra (untimed) f32-mode measurement")
+    ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra (untimed) f32-mode and resident measurements")
     ap.add_argument("--cpu-clips", type=int, default=12)
-    args = ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched N > 1 run (0 = pick a free one)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """N > 1 and not yet under torchrun: start the ranks as children of this (GPU-free) process and relay the result."""
+    from artalk_amd.dist import free_port      # imports torch, but touches no GPU
+    port = args.master_port or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching: " + " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode == 0 and line is None:
+        log("the ranks exited without printing a result line")
+        return 1
+    return proc.returncode
+
+
+def main():
+    args = parse_args()
+    world_env = int(os.environ.get("WORLD_SIZE", "0"))
+    if args.gpus > 1 and world_env == 0:
+        sys.exit(self_launch(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = max(world_env, 1)
+    if args.gpus != world:
+        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with: python -m torch.distributed.run --nnodes=1 "
-                     "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    from artalk_amd import dist as adist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    collective = world > 1 or args.force_collective
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+    elif collective:
+        adist.init_single_process_group("nccl", dev)
 
     from artalk_amd.config import ARTalkConfig
     from artalk_amd.model import BitwiseARModel
@@ -114,104 +169,147 @@ def main():
     log(f"rank {rank}: weights generated + loaded in {t_load:.1f} s")
 
     B = args.batch
-    seeds = [rank * B + i for i in range(B)]
-    audios = [torch.from_numpy(synth_audio(s, args.seconds)).to(dev) for s in seeds]     # resident in HBM
-    frames_per_clip = model.seq_length(audios[0].shape[0])
-    chunks = sum(model.n_chunks(a.shape[0]) for a in audios)
+    n_samples = int(round(args.seconds * 16000))
+    frames_per_clip = model.seq_length(n_samples)
+    chunks = B * model.n_chunks(n_samples)
     model.reserve(B, chunks)
     if args.overlap:
         model.set_overlap(True)
-    gathered = torch.empty(world * B, frames_per_clip, cfg.motion_dim, device=dev) if world > 1 else None
+
+    class ClipList:
+        """All world*B clips of the job, clip i = synth_audio(seed i); only the local shard is ever built (pinned host rows)."""
+        def __init__(self):
+            self.rows = {}
+
+        def __len__(self):
+            return world * B
+
+        def __getitem__(self, i):
+            if i not in self.rows:
+                self.rows[i] = torch.from_numpy(synth_audio(i, args.seconds)).pin_memory()
+            return self.rows[i]
+
+    clips = ClipList()
+    mine = adist.shard_range(len(clips), rank, world)
+    host_audio = [clips[i] for i in mine]                                         # pinned host memory
+    dev_audio = [a.to(dev) for a in host_audio]                                   # the same clips resident in HBM (--resident)
+    host_out = torch.empty(B, frames_per_clip, cfg.motion_dim).pin_memory()       # D2H target of the local codes
+    state = {"resident": args.resident}
+
+    def infer_fn(audios, styles):
+        src = dev_audio if state["resident"] else audios                         # host tensors: H2D happens inside inference_batch
+        return model.inference_batch(src, styles)
 
     def step():
-        outs = model.inference_batch(audios)
+        outs = adist.run_sharded(infer_fn, clips, None, gather=collective, max_frames=frames_per_clip, force_collective=args.force_collective)
+        local = outs[mine.start:mine.stop] if collective else outs
+        if not state["resident"]:
+            host_out.copy_(torch.stack(list(local)), non_blocking=True)         # D2H of this rank's codes
+        return local
+
+    def timed(n):
         if world > 1:
-            dist.all_gather_into_tensor(gathered, torch.stack(outs))     # result collection over xGMI (RCCL)
-        return outs
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            outs = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, outs
 
     for _ in range(args.warmup):
         outs = step()
     torch.cuda.synchronize()
     log("warmup done")
     model.set_profiling(1)       # light: hipGraphs stay on; HIP events bracket the eager launches of the dominant kernel
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        outs = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, outs = timed(args.steps)
     log(f"timed region done: {dt:.3f} s for {args.steps} steps")
     prof = model.get_profile()       # numbers of the last timed step
     model.set_profiling(0)
 
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+    rc = 0
+    if rank == 0:
+        total_frames = args.steps * B * frames_per_clip * world
+        value = total_frames / dt
+        # parity of the benchmarked batch against the reference's own outputs: every clip of rank 0 that has a golden
+        parity = None
+        if args.config == "full" and args.seconds == 10.0 and os.path.exists(GOLDEN_SET):
+            g = np.load(GOLDEN_SET)
+            f0, errs = 0, {}
+            res = host_out.numpy() if not state["resident"] else torch.stack(list(outs)).cpu().numpy()
+            for i in range(len(g["n_frames"])):
+                nf = int(g["n_frames"][i])
+                if int(g["style_seed"][i]) < 0 and int(g["seed"][i]) < B:         # the bench runs unstyled clips
+                    errs[int(g["seed"][i])] = float(np.abs(res[int(g["seed"][i])] - g["out"][f0:f0 + nf]).max())
+                f0 += nf
+            parity = {"fixture": "tests/golden/full_cfg2_synth8.npz (reference outputs)", "clips": sorted(errs),
+                      "flame_max_abs_err": max(errs.values()), "tolerance": 1e-3}
+            if not parity["flame_max_abs_err"] < 1e-3:
+                log(f"PARITY FAILURE: {errs}")
+                rc = 3
 
-    total_frames = args.steps * B * frames_per_clip * world
-    value = total_frames / dt
-    # parity of the benchmarked configuration against the reference golden (clip seed 0 == tests/golden/full_10s_s0)
-    parity = None
-    gpath = os.path.join(REPO, "tests", "golden", "full_10s_s0.npz")
-    if args.config == "full" and args.seconds == 10.0 and os.path.exists(gpath):
-        g = np.load(gpath)
-        parity = {"case": "full_10s_s0", "flame_max_abs_err": float(np.abs(outs[0].cpu().numpy() - g["out"]).max())}
+        dom_tflops = prof["dom_flop"] / (prof["dom_ms"] * 1e-3) / 1e12 if prof["dom_ms"] > 0 else 0.0
+        # HBM traffic per launch of the dominant kernel: from the committed PMC passes of this same command (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE, separate runs, corrected as MI355X_MICROARCH.md prescribes); a PMC pass cannot share a run with timing
+        traffic, traffic_src = None, None
+        tpath = os.path.join(REPO, PMC_TRAFFIC_FILE)
+        if os.path.exists(tpath):
+            for k, v in json.load(open(tpath)).items():
+                if isinstance(v, dict) and k.startswith(MODES[args.precision][1]):
+                    traffic, traffic_src = round(v["hbm_bytes_per_launch"]), PMC_TRAFFIC_FILE
+        dtype, _, kdesc, peak, peak_note = MODES[args.precision]
+        roofline = {
+            "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(dom_tflops / peak, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": kdesc, "peak_note": peak_note,
+            "launches": int(prof["dom_launches"]), "avg_launch_ms": round(prof["dom_ms"] / max(prof["dom_launches"], 1), 4),
+            "share_of_step_ms": round(prof["dom_ms"], 2),
+        }
+        io = ("audio resident in HBM, codes left in HBM" if state["resident"] else
+              "H2D of the audio from pinned host memory and D2H of the codes to pinned host memory inside every step")
+        result = {
+            "metric": "motion frames/sec (25 fps clips) at batch=32 per GPU", "value": round(value, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"configs[2]: batch={B} synthetic {args.seconds:g} s 16 kHz clips per GPU, {chunks} 4-s chunks, "
+                                   "hipGraph decode loop, deterministic synthetic weights (489.5 M params)",
+                       "clips_per_gpu": B, "frames_per_clip": frames_per_clip, "precision": args.precision,
+                       "model_config": args.config, "io": io,
+                       "collective": ("RCCL all_gather_into_tensor of the codes (backend nccl), world size %d" % world) if collective else None},
+            "fps_per_clip": round(value / (B * world), 1),
+            "algorithmic_tflops": round(value * GFLOP_PER_FRAME / 1e3, 2),
+            # overlapped schedule: the wav2vec2 buckets are measured on their own stream and run BESIDE ada/ar of the previous chunk
+            # index, so the buckets add up to more than total_ms; ada_ms includes waiting for the features of its chunk index
+            "schedule": "overlapped (wav2vec2 of chunk index j+1 beside the AR/VAE body of j)" if (args.overlap and B >= 8) else "sequential",
+            "stages_ms": {k: round(prof[k], 2) for k in ("style_ms", "w2v_conv_ms", "w2v_encoder_ms", "ada_ms", "ar_ms", "vae_ms", "total_ms")},
+            "roofline": roofline,
+            "parity": parity,
+            "load_s": round(t_load, 1),
+        }
 
-    dom_tflops = prof["dom_flop"] / (prof["dom_ms"] * 1e-3) / 1e12 if prof["dom_ms"] > 0 else 0.0
-    # HBM traffic per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of
-    # this same command, separate runs; profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes)
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath):
-        for k, v in json.load(open(tpath)).items():
-            if isinstance(v, dict) and k.startswith(MODES[args.precision][1]):
-                traffic = round(v["hbm_bytes_per_launch"])
-    dtype, _, kdesc, peak, peak_note = MODES[args.precision]
-    roofline = {
-        "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-        "frac": round(dom_tflops / peak, 4), "traffic": traffic, "kernel": kdesc, "peak_note": peak_note,
-        "launches": int(prof["dom_launches"]), "avg_launch_ms": round(prof["dom_ms"] / max(prof["dom_launches"], 1), 4),
-        "share_of_step_ms": round(prof["dom_ms"], 2),
-    }
-    result = {
-        "metric": "motion frames/sec (25 fps clips) at batch=32 per GPU", "value": round(value, 1), "unit": "frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-        "config": {"workload": f"configs[2]: batch={B} synthetic {args.seconds:g} s 16 kHz clips per GPU, {chunks} 4-s chunks, "
-                               "hipGraph decode loop, deterministic synthetic weights (489.5 M params)",
-                   "clips_per_gpu": B, "frames_per_clip": frames_per_clip, "precision": args.precision,
-                   "model_config": args.config},
-        "fps_per_clip": round(value / (B * world), 1),
-        "algorithmic_tflops": round(value * GFLOP_PER_FRAME / 1e3, 2),
-        # overlapped schedule: the wav2vec2 buckets are measured on their own stream and run BESIDE ada/ar of the previous chunk
-        # index, so the buckets add up to more than total_ms; ada_ms includes waiting for the features of its chunk index
-        "schedule": "overlapped (wav2vec2 of chunk index j+1 beside the AR/VAE body of j)" if (args.overlap and B >= 8) else "sequential",
-        "stages_ms": {k: round(prof[k], 2) for k in ("style_ms", "w2v_conv_ms", "w2v_encoder_ms", "ada_ms", "ar_ms", "vae_ms", "total_ms")},
-        "roofline": roofline,
-        "parity": parity,
-        "load_s": round(t_load, 1),
-    }
-
-    # the same workload in the other GEMM mode (exact fp32 MFMA), outside the timed region: the f32 kernel is MFMA-bound and
-    # sits much closer to its (6x lower) roofline, the f16x3 kernel is faster in absolute terms
-    if world == 1 and args.precision == "f16x3" and not args.no_alt_mode:
+    extras = world == 1 and not args.no_alt_mode
+    if extras and not args.resident:
+        # the same steps with the audio resident and the codes left in HBM (what round 1 reported): the PCIe share of the step
+        state["resident"] = True
+        step(); torch.cuda.synchronize()
+        dtr, _ = timed(max(2, args.steps // 2))
+        state["resident"] = False
+        n = max(2, args.steps // 2)
+        result["resident"] = {"value": round(n * B * frames_per_clip / dtr, 1), "ms_per_step": round(dtr / n * 1e3, 2)}
+    if extras and args.precision == "f16x3":
+        # the same workload in the other GEMM mode (exact fp32 MFMA), outside the timed region: the f32 kernel is MFMA-bound and
+        # sits much closer to its (6x lower) roofline, the f16x3 kernel is faster in absolute terms
         model.set_precision("f32")
         step(); torch.cuda.synchronize()
         model.set_profiling(1)
-        t1 = time.perf_counter()
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        dt32 = (time.perf_counter() - t1) / 2
+        dt32, _ = timed(2)
+        dt32 /= 2
         p32 = model.get_profile()
         model.set_profiling(0)
         model.set_precision("f16x3")
@@ -220,7 +318,7 @@ def main():
                               "roofline": {"bound": "mfma", "achieved": round(tf32, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                            "frac": round(tf32 / PEAK_F32_MFMA_TFLOPS, 4), "kernel": MODES["f32"][2]}}
 
-    if not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
         sys.path.insert(0, os.path.join(REPO, "oracle"))
         from artalk_oracle import ARTalkOracle
         cores = host_cores()
@@ -239,13 +337,15 @@ def main():
             if t_cpu > 12.0:
                 break
         result["cpu_baseline"] = {
-            "value": round(frames / t_cpu, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "value": round(frames / t_cpu, 1), "unit": "frames/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
             "sample": f"{n_done} of the same {args.seconds:g} s clips, batch 1 sequentially as the reference runs "
                       f"(no KV cache, fp32 torch-CPU), {t_cpu:.1f} s of CPU work",
         }
-    print(json.dumps(result), flush=True)
-    if world > 1:
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

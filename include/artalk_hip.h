@@ -15,8 +15,10 @@
  * Conventions: plain pointers and sizes only; all *_dev pointers are device memory on the model's GPU;
  * every call returns 0 on success or a negative ARTALK_E* code (text via artalk_last_error); the caller
  * owns every buffer it passes; the library owns weights and workspace; one model per GPU, calls on one
- * model are not thread-safe; work is enqueued on the hipStream_t passed as `stream` (NULL = default
- * stream) and artalk_infer returns without synchronising.
+ * model are not thread-safe; work is enqueued on the hipStream_t passed as `stream` (NULL = a stream the
+ * library owns) and artalk_infer / artalk_stream_* return without synchronising: the small host tables of a
+ * call (chunk offsets, style flags) go through a ring of pinned staging slots, so a call blocks only when
+ * four earlier calls are still in flight, or when it has to grow the workspace (artalk_reserve avoids that).
  *
  * The artalk_op_* entry points expose single kernels so that tests can check each one against the CPU
  * oracle through this same ABI; they are not needed by a binding.
@@ -37,6 +39,7 @@ extern "C" {
 #define ARTALK_EHIP (-4)        /* HIP runtime error                                  */
 #define ARTALK_ESTATE (-5)      /* call order (infer before finalize, ...)            */
 #define ARTALK_ECAPACITY (-6)   /* batch larger than the reserved workspace           */
+#define ARTALK_EBUSY (-7)       /* artalk_poll_status: the call is still running      */
 
 #define ARTALK_DTYPE_F32 0
 #define ARTALK_DTYPE_I64 1
@@ -74,7 +77,9 @@ int64_t artalk_weight_bytes(const artalk_model* m);
  *   audio_dev        [B][audio_clip_stride] f32, 16 kHz mono; clip b holds n_chunks[b]*64000 samples, zero padded
  *                    by the caller exactly as app/models.py:78-85 pads.
  *   n_chunks         host, [B], must be non-increasing (the host sorts clips; ragged batches stay dense prefixes).
- *   style_motion_dev [B][50][106] f32 or NULL; has_style host [B] (NULL = none): app/models.py:67-73.
+ *   style_motion_dev [B][50][106] f32 or NULL; has_style host [B] (NULL = none): app/models.py:67-73.  has_style[b] = 1: row b
+ *                    is a style clip; 2: the first 768 floats of row b are a condition computed by artalk_style_encode
+ *                    (the style-clip cache: the encoder is skipped); 0: no style (null_style_cond).
  *   out_motion_dev   [B][out_clip_stride] f32, receives n_chunks[b]*100 rows of 106 per clip (caller truncates
  *                    to ceil(N/640) rows, app/models.py:115).
  *   out_bits_dev     optional [B][max_chunks][181][32] u8: the 0/1 decisions of app/models.py:104 (last scale step).
@@ -84,6 +89,11 @@ int64_t artalk_weight_bytes(const artalk_model* m);
 int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_stride, const int64_t* n_chunks, int B,
                  const float* style_motion_dev, const uint8_t* has_style, float* out_motion_dev, int64_t out_clip_stride,
                  uint8_t* out_bits_dev, uint8_t* out_hist_bits_dev, float* out_w2v_dev, void* stream);
+
+/* Style condition of n style clips (app/models.py:67-73: StyleEncoder -> style_cond_embed -> 1.1 c - 0.1 null), for callers that
+ * keep one style across many calls as the reference's engine does (inference.py:41-45): style_motion_dev [n][50][106] ->
+ * out_cond_dev [n][768].  Pass a condition back through artalk_infer / artalk_stream_begin with has_style[b] = 2. */
+int artalk_style_encode(artalk_model* m, const float* style_motion_dev, int n, float* out_cond_dev, void* stream);
 
 /* Streaming form of the same path (chunk-at-a-time, history kept in the model between calls): the reference
  * loop body of app/models.py:92-114 for B parallel streams.  artalk_stream_begin computes the style condition and the initial
@@ -106,10 +116,15 @@ int artalk_flame_verts(artalk_flame* f, const float* betas_dev, const float* ful
 void artalk_flame_destroy(artalk_flame* f);
 const char* artalk_flame_last_error(const artalk_flame* f);
 
-/* Numerical health of the last artalk_infer (synchronises `stream`): bit 0 a logit was NaN/Inf (the pairwise argmax of
- * app/models.py:104 would silently turn it into a 0 bit), bit 1 a re-encoder output was NaN/Inf, bit 2 a FLAME code was NaN/Inf.  Non-zero in f16x3 mode means an
- * activation left fp16's range: redo the call in f32 mode (the Python host does). */
+/* Numerical health of the work enqueued since the last artalk_infer / artalk_stream_begin started.  Every call ends with an
+ * asynchronous copy of the device status word to pinned host memory.  artalk_get_status WAITS for that copy (an event wait:
+ * the one synchronisation on this boundary, paid only by callers that ask; `stream` is ignored); artalk_poll_status never
+ * blocks and returns ARTALK_EBUSY while the call is still running.  Bits: 0 a logit was NaN/Inf (the pairwise argmax of
+ * app/models.py:104 would silently turn it into a 0 bit), 1 a re-encoder output was NaN/Inf, 2 a FLAME code was NaN/Inf,
+ * 3 an activation exceeded the range of the P8 split format (|x| >= 4094) where it was produced.  Non-zero in f16x3 mode
+ * means an activation left fp16's range: redo the call in f32 mode (the Python host does, and stays in f32). */
 int artalk_get_status(artalk_model* m, int* flags, void* stream);
+int artalk_poll_status(artalk_model* m, int* flags);
 
 /* Savitzky-Golay smoothing of inference.py:89-95 on the device: in/out [T][106] f32, T >= 9. */
 int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, void* stream);
@@ -120,7 +135,8 @@ int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, v
  * LAST artalk_infer's numbers (milliseconds / counters):
  *   out[0] style  out[1] wav2vec2 conv stack  out[2] wav2vec2 encoder  out[3] AdaLN table GEMM
  *   out[4] AR scale steps (level 1: whole captured body)  out[5] VAE decode+re-encode (level 2 only; + initial history)
- *   out[6] total  out[7] bracketed launches of the dominant kernel (128x128-tile fp32 MFMA GEMM)  out[8] their summed ms
+ *   out[6] total  out[7] bracketed launches of the dominant kernel (f16x3 mode: gemm_p8_2wgp_kernel, the 128x128-tile LDS-DMA split GEMM of
+ *   the wav2vec2 encoder; f32 mode: the 128x128-tile fp32 MFMA GEMM)  out[8] their summed ms
  *   out[9] their summed FLOP */
 int artalk_set_profiling(artalk_model* m, int level);
 int artalk_get_profile(artalk_model* m, double* out, int n);

@@ -114,34 +114,92 @@ def run_case(model, sd, seed, seconds, with_style, audio_np=None):
     )
 
 
-DEMO = [("eng1", 4, True), ("eng2", 5, False)]     # (demo/<name>.wav, style seed, with style)
+# (demo/<name>.wav, style seed, with style): all six clips of the reference's demo/ directory (3.4 - 13.8 s, 1 - 4 chunks)
+DEMO = [("eng1", 4, True), ("eng2", 5, False), ("cn1", 6, False), ("cn2", 7, True), ("jp1", 8, True), ("jp2", 9, False)]
+DEMO_NAMES = ["cn1", "cn2", "eng1", "eng2", "jp1", "jp2"]      # sorted(demo/*.wav): the order config 5 cycles through
 
 
-def demo_cases(model, sd, fp, out_dir):
-    """Real speech (configs 1 and 5 of BASELINE.json): demo/*.wav -> 16 kHz mono with this repo's restatement of the
-    torchaudio resampler (oracle/audio_oracle.py), quantised to int16 so the input itself is a small committed fixture
-    (tests/golden/demo_16k_s16.npz); the reference then runs on exactly that array."""
+def demo_inputs():
+    """demo/*.wav -> 16 kHz mono with this repo's restatement of the torchaudio resampler (oracle/audio_oracle.py), quantised
+    to int16 so that the input itself is a small committed fixture (tests/golden/demo_16k_s16.npz)."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     from audio_oracle import load_mono_16k
     from artalk_amd.audio import read_wav
     inputs = {}
-    for name, seed, with_style in DEMO:
+    for name in DEMO_NAMES:
         wav, sr = read_wav(os.path.join(REFERENCE, "demo", name + ".wav"))
         a = load_mono_16k(wav, sr).numpy()
-        q = np.clip(np.round(a * 32768.0), -32768, 32767).astype(np.int16)
-        inputs[name] = q
+        inputs[name] = np.clip(np.round(a * 32768.0), -32768, 32767).astype(np.int16)
+    return inputs
+
+
+def stamp(g, fp):
+    g["weights_seed"] = np.int64(DEFAULT_SEED)
+    g["weights_fingerprint_keys"] = np.array(list(fp.keys()))
+    g["weights_fingerprint"] = np.array([fp[k] for k in fp], dtype=np.float64)
+    return g
+
+
+def demo_cases(model, sd, fp, out_dir, inputs):
+    """Real speech (configs 1 and 5 of BASELINE.json): the reference runs on exactly the committed 16 kHz arrays."""
+    for name, seed, with_style in DEMO:
+        q = inputs[name]
         audio = (q.astype(np.float32) / np.float32(32768.0))
-        g = run_case(model, sd, seed, len(q) / 16000.0, with_style, audio_np=audio)
-        g["weights_seed"] = np.int64(DEFAULT_SEED)
-        g["weights_fingerprint_keys"] = np.array(list(fp.keys()))
-        g["weights_fingerprint"] = np.array([fp[k] for k in fp], dtype=np.float64)
+        g = stamp(run_case(model, sd, seed, len(q) / 16000.0, with_style, audio_np=audio), fp)
         g["demo"] = np.array(name)
         path = os.path.join(out_dir, f"full_demo_{name}.npz")
         np.savez_compressed(path, **g)
         print(f"  full_demo_{name}: frames={g['out'].shape[0]} min logit margin={g['logit_margin'].min():.2e} "
               f"min hist margin={g['hist_margin'].min():.2e} -> {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
-    np.savez_compressed(os.path.join(out_dir, "demo_16k_s16.npz"), **inputs)
-    print("  demo inputs ->", os.path.getsize(os.path.join(out_dir, "demo_16k_s16.npz")) // 1024, "KiB", flush=True)
+
+
+SPARSE_TAU = 1e-3     # clip sets keep the reference's decision margins only where they are below this
+
+
+def run_set(model, sd, fp, clips, path):
+    """A set of clips in one compact fixture.  clips: list of (kind, key, style_seed | None) with kind 'demo' (key = wav name,
+    audio from `inputs`) or 'synth' (key = (seed, seconds)).  Per clip: FLAME codes, packed bits / history bits; the decision
+    margins are kept sparsely (positions below SPARSE_TAU), which is all a parity test needs of them."""
+    outs, bits, hist, nfr, nch = [], [], [], [], []
+    lm_idx, lm_val, hm_idx, hm_val = [], [], [], []
+    c_off, h_off, t_ref = 0, 0, 0.0
+    for kind, audio_np, seed, seconds, style_seed in clips:
+        g = run_case(model, sd, seed if style_seed is None else style_seed, seconds, style_seed is not None, audio_np=audio_np)
+        t_ref += float(g["ref_seconds"])
+        outs.append(g["out"]); bits.append(g["bits"]); hist.append(g["hist_bits"])
+        nfr.append(g["out"].shape[0]); nch.append(g["bits"].shape[0])
+        for marg, idxs, vals, off in ((g["logit_margin"], lm_idx, lm_val, c_off), (g["hist_margin"], hm_idx, hm_val, h_off)):
+            w = np.argwhere(marg.astype(np.float32) < SPARSE_TAU)
+            vals.append(marg[tuple(w.T)].astype(np.float32))
+            w[:, 0] += off
+            idxs.append(w.astype(np.int32))
+        c_off += nch[-1]; h_off += nch[-1] + 1
+    g = stamp(dict(
+        out=np.concatenate(outs), bits=np.concatenate(bits), hist_bits=np.concatenate(hist),
+        n_frames=np.array(nfr, np.int32), n_chunks=np.array(nch, np.int32),
+        logit_margin_idx=np.concatenate(lm_idx), logit_margin_val=np.concatenate(lm_val),
+        hist_margin_idx=np.concatenate(hm_idx), hist_margin_val=np.concatenate(hm_val),
+        sparse_tau=np.float64(SPARSE_TAU),
+        kind=np.array([c[0] for c in clips]), seed=np.array([c[2] for c in clips], np.int64),
+        seconds=np.array([c[3] for c in clips], np.float64),
+        style_seed=np.array([-1 if c[4] is None else c[4] for c in clips], np.int64),
+        ref_seconds=np.float64(t_ref)), fp)
+    np.savez_compressed(path, **g)
+    print(f"  {os.path.basename(path)}: {len(clips)} clips, {sum(nfr)} frames, {sum(nch)} chunks, reference took {t_ref:.0f} s; "
+          f"decisions with margin < {SPARSE_TAU}: {len(g['logit_margin_val'])} logit / {len(g['hist_margin_val'])} history "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
+def clip_sets(model, sd, fp, out_dir, inputs):
+    # BASELINE configs[4]: 32 clips cycling the six demo wavs, every clip with its own synthetic style clip (seed 200 + i)
+    clips = []
+    for i in range(32):
+        q = inputs[DEMO_NAMES[i % 6]]
+        clips.append((DEMO_NAMES[i % 6], q.astype(np.float32) / np.float32(32768.0), i, len(q) / 16000.0, 200 + i))
+    run_set(model, sd, fp, clips, os.path.join(out_dir, "full_cfg4_demo32.npz"))
+    # BASELINE configs[2]: the first 8 of the 32 synthetic 10 s clips of the throughput run (seeds 0..7; odd seeds styled)
+    clips = [("synth", None, i, 10.0, (i if i % 2 else None)) for i in range(8)]
+    run_set(model, sd, fp, clips, os.path.join(out_dir, "full_cfg2_synth8.npz"))
 
 
 def main():
@@ -149,6 +207,8 @@ def main():
     ap.add_argument("--cases", default="tiny,full")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--only-demo", action="store_true")
+    ap.add_argument("--only-sets", action="store_true")
+    ap.add_argument("--no-sets", action="store_true")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
@@ -162,12 +222,9 @@ def main():
         print(f"[{cfg_name}] reference constructed + strict load in {time.time() - t0:.1f}s", flush=True)
         fp = fingerprint(sd)
         for name, c, seed, seconds, with_style in CASES:
-            if c != cfg_name or args.only_demo:
+            if c != cfg_name or args.only_demo or args.only_sets:
                 continue
-            g = run_case(model, sd, seed, seconds, with_style)
-            g["weights_seed"] = np.int64(DEFAULT_SEED)
-            g["weights_fingerprint_keys"] = np.array(list(fp.keys()))
-            g["weights_fingerprint"] = np.array([fp[k] for k in fp], dtype=np.float64)
+            g = stamp(run_case(model, sd, seed, seconds, with_style), fp)
             g["versions"] = np.array([torch.__version__, np.__version__])
             path = os.path.join(args.out, name + ".npz")
             np.savez_compressed(path, **g)
@@ -175,7 +232,13 @@ def main():
                   f"min logit margin={g['logit_margin'].min():.2e} min hist margin={g['hist_margin'].min():.2e} "
                   f"-> {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
         if cfg_name == "full":
-            demo_cases(model, sd, fp, args.out)
+            inputs = demo_inputs()
+            np.savez_compressed(os.path.join(args.out, "demo_16k_s16.npz"), **inputs)
+            print("  demo inputs ->", os.path.getsize(os.path.join(args.out, "demo_16k_s16.npz")) // 1024, "KiB", flush=True)
+            if not args.only_sets:
+                demo_cases(model, sd, fp, args.out, inputs)
+            if not args.no_sets:
+                clip_sets(model, sd, fp, args.out, inputs)
         del model, sd
 
 

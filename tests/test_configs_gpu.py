@@ -1,0 +1,98 @@
+"""BASELINE.json configs[2] and configs[4] on the GPU at their full sizes (full 489.5 M-parameter model, batch 32), every clip
+that has a reference golden compared over its whole length.
+
+configs[4]: 32 clips cycling the reference's six demo/*.wav (3.4 - 13.8 s => 1 - 4 chunks, ragged), clip_length = 750, every
+clip with its own style clip (synthetic mean + std * N(0,1): the real assets/style_motion/*.pt are not available offline).
+The golden set tests/golden/full_cfg4_demo32.npz is the reference's own output for each of the 32 (wav, style) pairs
+(oracle/make_golden.py::clip_sets).  configs[2]: 32 synthetic 10 s clips (the throughput run of bench.py); seeds 0..7 have
+reference goldens (tests/golden/full_cfg2_synth8.npz, odd seeds styled), the rest are checked against their batch-1 runs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import (FLAME_TOL, assert_clip_parity, clip_set_inputs, get_gpu_model, get_state_dict, load_clip_set, load_golden)
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_set(m, audios, styles):
+    outs = m.inference_batch(audios, styles, return_aux=True)
+    aux = m.last_aux
+    return [o.cpu().numpy() for o in outs], [b.cpu().numpy() for b in aux["bits"]], [h.cpu().numpy() for h in aux["hist_bits"]]
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_config4_demo_wavs_batch32_styled(precision):
+    clips = load_clip_set("full_cfg4_demo32")
+    assert len(clips) == 32 and all(c["style_seed"] >= 0 for c in clips)
+    cfg, sd = get_state_dict("full")
+    audios, styles = clip_set_inputs(clips, sd)
+    m = get_gpu_model("full")
+    m.set_precision(precision)
+    try:
+        outs, bits, hist = _run_set(m, audios, styles)          # ONE inference_batch call, ragged, per-clip style
+    finally:
+        m.set_precision("f32")
+    worst, chunks = 0.0, 0
+    for i, c in enumerate(clips):
+        good, n, err = assert_clip_parity(f"cfg4 clip {i} ({c['kind']}, style {c['style_seed']})", precision, outs[i], bits[i], hist[i],
+                                          c["out"], c["bits"], c["hist_bits"], c["logit_margin"], c["hist_margin"])
+        worst, chunks = max(worst, err), chunks + good
+    print(f"configs[4] [{precision}]: 32 clips, {chunks} chunks decision-exact, worst FLAME max-abs err {worst:.3e}")
+    assert chunks == sum(c["bits"].shape[0] for c in clips) == 96
+
+
+def test_config4_engine_surface():
+    """The engine-level call of config 5 (reference inference.py:47-57: clip_length = 750, style set on the engine, savgol,
+    dims 104: zeroed) for one demo clip against the reference's smoothed output."""
+    from artalk_amd.engine import ARTAvatarInferEngine
+    from conftest import golden_inputs
+    cfg, sd = get_state_dict("full")
+    g = load_golden("full_demo_cn2")
+    audio, style = golden_inputs(g, sd)
+    eng = ARTAvatarInferEngine(load_gaga=False, fix_pose=False, clip_length=750, device="cuda", state_dict=sd, config=cfg,
+                               model=get_gpu_model("full"))
+    eng.ARTalk.set_precision("f16x3")
+    try:
+        eng.set_style_motion(style)
+        pred = eng.inference(audio).cpu().numpy()
+    finally:
+        eng.ARTalk.set_precision("f32")
+    assert pred.shape == g["engine_out"].shape == (240, 106)
+    err = np.abs(pred - g["engine_out"]).max()
+    assert err < FLAME_TOL, f"engine output differs by {err:.3e}"
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_config2_batch32_synthetic_10s(precision):
+    from artalk_amd.synth import synth_audio, synth_style
+    clips = load_clip_set("full_cfg2_synth8")
+    cfg, sd = get_state_dict("full")
+    mean, std = sd["basic_vae.motion_mean"].numpy(), sd["basic_vae.motion_std"].numpy()
+    # the 32 clips of bench.py (seeds 0..31); odd seeds below 8 styled as in the golden set, plus a few more styled ones
+    audios = [torch.from_numpy(synth_audio(s, 10.0)) for s in range(32)]
+    styles = [torch.from_numpy(synth_style(s, mean, std)) if (s % 2 == 1 and (s < 8 or s % 5 == 0)) else None for s in range(32)]
+    m = get_gpu_model("full")
+    m.set_precision(precision)
+    try:
+        outs, bits, hist = _run_set(m, audios, styles)
+        worst = 0.0
+        for i, c in enumerate(clips):                      # seeds 0..7 against the reference itself
+            good, n, err = assert_clip_parity(f"cfg2 clip {i}", precision, outs[i], bits[i], hist[i], c["out"], c["bits"], c["hist_bits"],
+                                              c["logit_margin"], c["hist_margin"])
+            worst = max(worst, err)
+        for case, i in (("full_10s_s0", 0), ("full_10s_s1_style", 1)):      # the two single-clip fixtures are the same clips
+            g = load_golden(case)
+            assert np.abs(outs[i] - g["out"]).max() < FLAME_TOL
+        # clips without a golden: identical decisions and codes to rounding as their batch-1 runs
+        for i in (9, 15, 22, 31):
+            so, sb, sh = _run_set(m, [audios[i]], [styles[i]])
+            assert (sb[0] == bits[i]).all() and (sh[0] == hist[i]).all(), f"clip {i}: decisions differ between batch 32 and batch 1"
+            assert np.abs(so[0] - outs[i]).max() < 1e-5
+        # the same batch twice is bit-identical (deterministic split-K, no atomics)
+        again = m.inference_batch(audios, styles)
+        assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(again, outs))
+    finally:
+        m.set_precision("f32")
+    print(f"configs[2] [{precision}]: 8 golden clips decision-exact, worst FLAME max-abs err {worst:.3e}")

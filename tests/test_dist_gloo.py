@@ -8,13 +8,13 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from artalk_amd.dist import gather_clips, run_sharded, shard_range
+from artalk_amd.dist import gather_clips, run_sharded, seq_length, shard_range
 
 
 def _fake_infer(audios, styles):
     outs = []
     for a in audios:
-        T = -(-a.shape[0] * 25 // 16000)
+        T = seq_length(a.shape[0])
         outs.append(a[:1].repeat(T, 106) + torch.arange(T, dtype=torch.float32)[:, None])
     return outs
 
@@ -39,17 +39,82 @@ def _free_port():
     return p
 
 
-def _run(n_clips):
+def _run(n_clips, worker=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker or _worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, True), (1, True)]
+
+
+class _LazyClips:
+    """What bench.py passes: len() + indexing, clips built on demand (only the local shard should ever be built)."""
+    def __init__(self, n):
+        self.n, self.built = n, []
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        self.built.append(i)
+        return torch.full((16000 + 640 * i,), float(i + 1))
+
+
+def _worker_lazy(rank, world, port, n_clips, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    clips = _LazyClips(n_clips)
+    res = run_sharded(_fake_infer, clips, None, gather=True, max_frames=seq_length(16000 + 640 * (n_clips - 1)))
+    want = _fake_infer([torch.full((16000 + 640 * i,), float(i + 1)) for i in range(n_clips)], None)
+    ok = len(res) == n_clips and all(torch.equal(r, w) for r, w in zip(res, want))
+    ok = ok and sorted(clips.built) == list(shard_range(n_clips, rank, world))       # nothing but the local shard was built
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def _worker_single(rank, world, port, n_clips, q):
+    from artalk_amd.dist import init_single_process_group
+    os.environ["MASTER_PORT"] = str(port)
+    init_single_process_group("gloo")
+    audios = [torch.full((16000 + 640 * i,), float(i + 1)) for i in range(n_clips)]
+    calls = []
+    orig = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    res = run_sharded(_fake_infer, audios, None, gather=True, force_collective=True)
+    dist.all_gather_into_tensor = orig
+    want = _fake_infer(audios, None)
+    ok = len(calls) == 2 and all(torch.equal(r, w) for r, w in zip(res, want))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_lazy_clip_list_world2():
+    _run(7, _worker_lazy)
+
+
+def test_force_collective_single_rank():
+    """bench.py --force-collective: a world-size-1 group still runs the two all-gathers (here on gloo; the -m gpu test runs
+    the same code on RCCL)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_single, args=(0, 1, _free_port(), 3, q))
+    p.start()
+    assert q.get(timeout=120) == (0, True)
+    p.join(timeout=60)
+
+
+def test_seq_length_is_the_models_formula():
+    """The gather buffer is sized with the float formula of app/models.py:66, not an integer ceil (they differ by one frame
+    where N/16000*25 rounds up in floating point)."""
+    import math
+    for n in (1, 639, 640, 641, 64000, 64640, 160000, 221184, 16000 * 13 + 7):
+        assert seq_length(n) == math.ceil(n / 16000 * 25.0)
 
 
 def test_shard_range_partitions():

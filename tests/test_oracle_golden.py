@@ -89,3 +89,25 @@ def test_kv_cache_is_legal():
         seen = bits
         if pidx < 4:
             nxt = torch.cat([style_cond, F.linear(o.vqidx_to_ar_vqfeat(pidx, bits), w["vqfeat_embed.weight"], w["vqfeat_embed.bias"])], 1)
+
+
+@pytest.mark.parametrize("name,index", [("full_cfg4_demo32", 3), ("full_cfg4_demo32", 27), ("full_cfg2_synth8", 1)])
+def test_oracle_matches_reference_clip_sets(name, index):
+    """The compact clip-set fixtures (BASELINE configs[4]: 32 styled demo clips; configs[2]: 8 synthetic 10 s clips) are the
+    reference's output too: spot-check clips of them with the oracle through the same loader the GPU tests use
+    (clip 3 / 27 = demo/eng2.wav with style seeds 203 / 227, one chunk each; clip 1 = 10 s, seed 1, styled)."""
+    from conftest import clip_set_inputs, load_clip_set
+    clips = load_clip_set(name)
+    cfg, sd = get_state_dict("full")
+    audios, styles = clip_set_inputs(clips, sd)
+    c = clips[index]
+    rec = {}
+    out = get_oracle("full").inference({"audio": audios[index][None], "style_motion": styles[index][None]}, record=rec)[0].numpy()
+    assert out.shape == c["out"].shape
+    assert (torch.cat(rec["bits"]).numpy().astype(np.uint8) == c["bits"]).all()
+    assert (torch.cat(rec["hist_bits"]).numpy().astype(np.uint8) == c["hist_bits"]).all()
+    assert np.abs(out - c["out"]).max() < 1e-5
+    # sparse margins: every listed margin is below the threshold, everything else reads as the threshold
+    mask = np.zeros((181, 32), bool)
+    mask[0, 0] = True
+    assert c["logit_margin"](0, mask).shape == (1,)
