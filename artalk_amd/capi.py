@@ -19,7 +19,7 @@ DTYPE_F32, DTYPE_I64 = 0, 1
 # every symbol include/artalk_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "artalk_create", "artalk_destroy", "artalk_last_error", "artalk_set_tensor", "artalk_finalize_weights",
-    "artalk_reserve", "artalk_workspace_bytes", "artalk_weight_bytes", "artalk_infer", "artalk_get_status", "artalk_poll_status", "artalk_style_encode", "artalk_stream_begin", "artalk_stream_chunk", "artalk_savgol", "artalk_flame_create", "artalk_flame_verts", "artalk_flame_destroy", "artalk_flame_last_error",
+    "artalk_reserve", "artalk_workspace_bytes", "artalk_weight_bytes", "artalk_infer", "artalk_get_status", "artalk_poll_status", "artalk_style_encode", "artalk_stream_begin", "artalk_stream_chunk", "artalk_stream_end", "artalk_savgol", "artalk_flame_create", "artalk_flame_verts", "artalk_flame_destroy", "artalk_flame_last_error",
     "artalk_set_profiling", "artalk_get_profile", "artalk_set_graphs", "artalk_set_overlap", "artalk_set_precision",
     "artalk_op_gemm", "artalk_op_gemm_ex", "artalk_op_gemm_f16s", "artalk_op_pack_split", "artalk_op_gemm_f16s_packed", "artalk_op_mfma_f32_peak", "artalk_op_layernorm", "artalk_op_attention", "artalk_op_w2v_front", "artalk_op_resample_mean", "artalk_op_pool_silu",
     "artalk_op_bsq_history",
@@ -108,6 +108,8 @@ def lib() -> C.CDLL:
     L.artalk_style_encode.restype = i32
     L.artalk_stream_begin.argtypes = [vp, i32, vp, vp, vp]
     L.artalk_stream_begin.restype = i32
+    L.artalk_stream_end.argtypes = [vp]
+    L.artalk_stream_end.restype = i32
     L.artalk_stream_chunk.argtypes = [vp, vp, i64, vp, i64, vp]
     L.artalk_stream_chunk.restype = i32
     L.artalk_flame_create.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, C.POINTER(vp)]

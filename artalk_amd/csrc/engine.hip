@@ -1268,6 +1268,12 @@ int artalk_stream_chunk(artalk_model* m, const float* audio_dev, int64_t chunk_s
     return ARTALK_OK;
 }
 
+int artalk_stream_end(artalk_model* m) {
+    if (!m) return ARTALK_EINVAL;
+    m->stream_B = 0;      // the history in the workspace is dead; artalk_style_encode / artalk_reserve may use the workspace again
+    return ARTALK_OK;
+}
+
 // Numerical health of the work enqueued since the last artalk_infer / artalk_stream_begin started.  Every call ends with an
 // asynchronous copy of the device status word into pinned host memory; artalk_get_status waits for that copy (the only
 // synchronisation on this boundary, and only if the caller asks), artalk_poll_status never blocks (ARTALK_EBUSY while the call is

@@ -287,7 +287,7 @@ class BitwiseARModel:
                 self._stream = torch.cuda.Stream(device=dev)
             caller = torch.cuda.current_stream()
             self._stream.wait_stream(caller)
-            self._n_streams = 0        # artalk_style_encode refuses to run inside a session
+            self.stream_end()          # artalk_style_encode refuses to run inside a session
             style_t, has = self._style_rows(style_motions, list(range(n_streams)), n_streams)
             self._stream.wait_stream(caller)
             rc = capi.lib().artalk_stream_begin(self._h, int(n_streams), capi.ptr(style_t),
@@ -330,7 +330,7 @@ class BitwiseARModel:
             raise RuntimeError("artalk_stream_chunk failed: " + self._err())
         if self._precision == "f16x3" and self.check_finite and self.status() != 0:
             # the history of the session already contains the damaged chunk: the session cannot be repaired in place
-            self._n_streams = 0
+            self.stream_end()
             self._trip_to_f32("streaming chunk")
             raise RuntimeError("artalk_amd: an activation left fp16's range during a streaming chunk; the model is now in f32 "
                                "mode - begin the streaming session again")
@@ -350,6 +350,8 @@ class BitwiseARModel:
     def stream_end(self):
         """Close the streaming session (history is dropped)."""
         self._n_streams = 0
+        if self._h is not None:
+            capi.lib().artalk_stream_end(self._h)
 
     # ------------------------------------------------------------------ geometry of app/models.py:66,78-80
     def seq_length(self, n_samples: int) -> int:
@@ -387,7 +389,7 @@ class BitwiseARModel:
         if B == 0:
             return []
         dev = self._device
-        self._n_streams = 0          # a batch call ends a streaming session (shared workspace)
+        self.stream_end()            # a batch call ends a streaming session (shared workspace)
         packed = isinstance(audios, torch.Tensor)      # (B, N): equal-length clips in one tensor -> one H2D copy, no per-clip loop
         if packed and (audios.dim() != 2 or audios.shape[1] == 0):
             raise ValueError("a packed batch must be a (B, N) float tensor of 16 kHz samples")

@@ -99,7 +99,9 @@ int artalk_style_encode(artalk_model* m, const float* style_motion_dev, int n, f
  * loop body of app/models.py:92-114 for B parallel streams.  artalk_stream_begin computes the style condition and the initial
  * history (app/models.py:67-73,86-89); every artalk_stream_chunk consumes the next 64000 samples of each stream
  * (audio_dev [B][chunk_stride], zero padded by the caller at the end of a clip) and writes 100 x 106 codes per stream to
- * out_motion_dev [B][out_stride].  A call to artalk_infer ends the streaming session (shared workspace). */
+ * out_motion_dev [B][out_stride].  artalk_stream_end, a new artalk_stream_begin or a call to artalk_infer ends the session
+ * (shared workspace); growing the workspace (artalk_reserve) ends it too, and artalk_stream_chunk then fails with ARTALK_ESTATE. */
+int artalk_stream_end(artalk_model* m);
 int artalk_stream_begin(artalk_model* m, int B, const float* style_motion_dev, const uint8_t* has_style, void* stream);
 int artalk_stream_chunk(artalk_model* m, const float* audio_dev, int64_t chunk_stride, float* out_motion_dev, int64_t out_stride,
                         void* stream);

@@ -160,34 +160,39 @@ class ARTalkOracle:
         out = "code_mapping" if side == "encoder" else "out_mapping"
         return F.linear(x, w[f"basic_vae.{side}.{out}.weight"], w[f"basic_vae.{side}.{out}.bias"])
 
-    def bsq(self, f):
+    def bsq(self, f, flips=()):
         # app/modules/bitwise_vae.py:316-334 (losses are computed and discarded by the caller)
         z = F.normalize(f, dim=-1)
         q_scale = 1.0 / (self.cfg.code_dim ** 0.5)
-        zhat = q_scale * torch.where(z > 0, torch.tensor(1.0), torch.tensor(-1.0))
+        sign = torch.where(z > 0, torch.tensor(1.0), torch.tensor(-1.0))
+        for row, bit in flips:       # test-fixture derivation only (oracle/make_alt_golden.py): take the OTHER sign at a decision
+            sign[:, row, bit] = -sign[:, row, bit]          # whose margin |z| is at rounding level
+        zhat = q_scale * sign
         q = z + (zhat - z)
         return q, (q > 0).int(), z
 
-    def ms_bsq(self, f):
-        # app/modules/bitwise_vae.py:227-242 MultiScaleBSQ.forward
+    def ms_bsq(self, f, flips=()):
+        # app/modules/bitwise_vae.py:227-242 MultiScaleBSQ.forward; flips: (token of the 181, bit) decisions to invert (see bsq)
         B, T, C = f.shape
         residual = f
         bits, margins = [], []
+        off = 0
         for pt in self.patch_nums:
             r = F.interpolate(residual.permute(0, 2, 1), size=(pt), mode="area").permute(0, 2, 1).contiguous() if pt != T else residual
-            q, b, z = self.bsq(r)
+            q, b, z = self.bsq(r, [(t - off, c) for t, c in flips if off <= t < off + pt])
+            off += pt
             q = F.interpolate(q.permute(0, 2, 1), size=(T), mode="linear").permute(0, 2, 1).contiguous() if pt != T else q
             residual = residual - q
             bits.append(b)
             margins.append(z.abs())
         return torch.cat(bits, dim=1), torch.cat(margins, dim=1)
 
-    def quant_to_vqidx(self, motion):
+    def quant_to_vqidx(self, motion, flips=()):
         # app/modules/bitwise_vae.py:78-93, this_motion=None branch
         w, T = self.w, self.cfg.frames_per_chunk
         enc_in = (motion - w["basic_vae.motion_mean"]) / w["basic_vae.motion_std"]      # :59-61
         enc_out = self.vae_stack("encoder", enc_in + w["basic_vae.enc_pos_embed"][:, :T], w["basic_vae.attn_mask"][:, :, :T, :T])
-        return self.ms_bsq(enc_out)
+        return self.ms_bsq(enc_out, flips)
 
     def bits_to_h(self, bits):
         return (bits.float() * 2 - 1.0) / (self.cfg.code_dim ** 0.5)
@@ -261,8 +266,11 @@ class ARTalkOracle:
 
     # ------------------------------------------------------------------ full path
     @torch.no_grad()
-    def inference(self, batch, record=None):
-        """app/models.py:62-121 (with_gtmotion=False).  ``record`` (dict) collects per-chunk internals."""
+    def inference(self, batch, record=None, force_hist=None):
+        """app/models.py:62-121 (with_gtmotion=False).  ``record`` (dict) collects per-chunk internals.  ``force_hist``
+        ({history index: [(token, bit), ...]}) inverts the listed history decisions - used only to derive the continuation of a
+        clip after a rounding-level flip (oracle/make_alt_golden.py); the default is the reference's arithmetic."""
+        force_hist = force_hist or {}
         w, cfg, pn = self.w, self.cfg, self.patch_nums
         audio = batch["audio"]
         B = audio.shape[0]
@@ -283,7 +291,7 @@ class ARTalkOracle:
         chunk_len = int(pn[-1] / 25.0 * 16000)
         chunks = torch.cat([audio, audio.new_zeros(B, padded_audio - audio.shape[1])], dim=-1).split(chunk_len, dim=-1)
         prev_motion = audio.new_zeros(B, pn[-1], cfg.motion_dim)
-        prev_bits, hist_margin = self.quant_to_vqidx(prev_motion)
+        prev_bits, hist_margin = self.quant_to_vqidx(prev_motion, force_hist.get(0, ()))
         prev_vqfeat = self.vqidx_to_feat(prev_bits, True)
         prev_attn_feat = torch.cat([style_cond, F.linear(prev_vqfeat, w["vqfeat_embed.weight"], w["vqfeat_embed.bias"])], dim=1)
         if record is not None:
@@ -310,7 +318,7 @@ class ARTalkOracle:
                     nxt = torch.cat([style_cond, F.linear(nxt, w["vqfeat_embed.weight"], w["vqfeat_embed.bias"])], dim=1)
             _, pred = self.vqidx_to_motion(prev_bits, bits)
             out.append(pred)
-            new_prev_bits, hm = self.quant_to_vqidx(pred)
+            new_prev_bits, hm = self.quant_to_vqidx(pred, force_hist.get(len(out), ()))
             if record is not None:
                 record["bits"].append(bits.clone())
                 record["logit_margin"].append((pairs[..., 0] - pairs[..., 1]).abs().clone())

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (FLAME_TOL, assert_clip_parity, clip_set_inputs, get_gpu_model, get_state_dict, load_clip_set, load_golden)
+from conftest import (FLAME_TOL, assert_clip_parity, clip_set_inputs, get_gpu_model, get_state_dict, load_alt, load_clip_set, load_golden)
 
 pytestmark = pytest.mark.gpu
 
@@ -34,10 +34,15 @@ def test_config4_demo_wavs_batch32_styled(precision):
         outs, bits, hist = _run_set(m, audios, styles)          # ONE inference_batch call, ragged, per-clip style
     finally:
         m.set_precision("f32")
+    # clip 5 (jp2, style 205): the reference's own margin at history decision (1, token 79, bit 25) is |z| = 1.2e-7, and the GPU
+    # takes the other sign there; the rest of that clip is held to the continuation the reference's arithmetic gives with that
+    # decision inverted (oracle/make_alt_golden.py) - in which (2, token 56, bit 8) has a margin of 4.1e-7 and flips again, hence
+    # a chain of two stages.  Every other clip must equal the reference golden outright.
+    alts = {5: [load_alt("full_cfg4_demo32_alt5_1"), load_alt("full_cfg4_demo32_alt5_2")]}
     worst, chunks = 0.0, 0
     for i, c in enumerate(clips):
         good, n, err = assert_clip_parity(f"cfg4 clip {i} ({c['kind']}, style {c['style_seed']})", precision, outs[i], bits[i], hist[i],
-                                          c["out"], c["bits"], c["hist_bits"], c["logit_margin"], c["hist_margin"])
+                                          c["out"], c["bits"], c["hist_bits"], c["logit_margin"], c["hist_margin"], alt=alts.get(i))
         worst, chunks = max(worst, err), chunks + good
     print(f"configs[4] [{precision}]: 32 clips, {chunks} chunks decision-exact, worst FLAME max-abs err {worst:.3e}")
     assert chunks == sum(c["bits"].shape[0] for c in clips) == 96

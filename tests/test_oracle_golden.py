@@ -111,3 +111,18 @@ def test_oracle_matches_reference_clip_sets(name, index):
     mask = np.zeros((181, 32), bool)
     mask[0, 0] = True
     assert c["logit_margin"](0, mask).shape == (1,)
+
+
+def test_forced_decision_continuation_fixture():
+    """tests/golden/full_cfg4_demo32_alt5_1.npz (oracle/make_alt_golden.py): identical to the reference run of that clip up to the
+    forced decision, whose reference margin is at rounding level; the loader the GPU test uses reads it back."""
+    from conftest import TAU_HIST, load_alt, load_clip_set
+    alt = load_alt("full_cfg4_demo32_alt5_1")
+    c = load_clip_set("full_cfg4_demo32")[alt["clip"]]
+    h0, (tok, bit) = alt["forced_hist"], alt["forced_pos"]
+    assert (alt["hist_bits"][:h0] == c["hist_bits"][:h0]).all() and (alt["bits"][:h0] == c["bits"][:h0]).all()
+    assert np.abs(alt["out"][:h0 * 100] - c["out"][:h0 * 100]).max() == 0.0
+    assert alt["hist_bits"][h0, tok, bit] != c["hist_bits"][h0, tok, bit]
+    mask = np.zeros((181, 32), bool)
+    mask[tok, bit] = True
+    assert c["hist_margin"](h0, mask)[0] < TAU_HIST
