@@ -13,6 +13,8 @@
 #include "kernels.h"
 #include "../../include/artalk_hip.h"
 
+#include <rocprofiler-sdk-roctx/roctx.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -32,6 +34,17 @@ constexpr int kE = 768;      // embed dim (app/models.py:19)
 constexpr int kCond = 1024;  // audio feature dim (app/models.py:27)
 constexpr int kNTok = 181;
 constexpr int kMaxLv = 5;
+
+// roctx range around one kernel group of the path (SURVEY.md section 5, K-groups): visible with `rocprofv3 --marker-trace`.
+// Host-side ranges: they bracket the ENQUEUE of the group (the path is asynchronous); inside a hipGraph capture nothing is
+// enqueued at replay time, so the captured body shows up as one "body.graph" range per clip group and its inner ranges
+// appear only when graphs are off (artalk_set_graphs(0) / profiling level 2).
+struct Range {
+    explicit Range(const char* name) { roctxRangePushA(name); }
+    ~Range() { roctxRangePop(); }
+    Range(const Range&) = delete;
+    Range& operator=(const Range&) = delete;
+};
 
 enum SlotKind { SK_DIRECT, SK_PADK, SK_CONV, SK_HOST, SK_IGNORE };
 
@@ -433,6 +446,8 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     // format (same bytes), so the big GEMMs can stage both operands with LDS-DMA (gemm_p8_2wgp_kernel / gemm_p8_256_kernel).
     const int p8 = m->precision == 1 ? 1 : 0;
     const int AP = p8 ? LF_A_P8 : 0;
+    Range r_w2v("artalk.wav2vec2");
+    roctxRangePushA("artalk.wav2vec2.conv_stack");      // K1-K3: normalise, conv0+LN+GELU, conv1-6 as GEMMs + LN + GELU
     launch_audio_normalize(audio, w.src_off + c0, w.xnorm, n, kSamplesPerChunk, s);
     launch_conv0(w.xnorm, kSamplesPerChunk, m->conv0_w, m->conv_b[0], m->conv_lnw[0], m->conv_lnb[0], w.convA, n, m->conv_T[0],
                  m->conv_S[0], s, p8);
@@ -447,6 +462,8 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
         std::swap(src, dst);
     }
     stage_mark(m, s, PB_CONV);
+    roctxRangePop();
+    Range r_enc("artalk.wav2vec2.encoder");             // K4-K7: projection, pos-conv, 24 layers, final LN, pooling + SiLU
     const int M = n * m->Ts;
     // feature projection (hf:429-434)
     layernorm(src, dst, m->fp_lnw, m->fp_lnb, M, CD, c.w2v_ln_eps, ACT_NONE, s, p8);
@@ -494,6 +511,7 @@ void run_style(artalk_model* m, const float* style_motion, int B, hipStream_t s,
     const artalk_config& c = m->cfg;
     Workspace& w = m->ws;
     const int S = c.style_dim, L = c.style_len, M = B * L;
+    Range r_style("artalk.style_encoder");
     if (style_motion && encode) {
         launch_style_input(style_motion, m->st_mean, m->st_std, w.s_in, B, s);
         linear(m, w.s_in, 128, m->st_proj_w, m->st_proj_b, w.s_h, S, M, S, 128, ACT_NONE, nullptr, s);
@@ -550,6 +568,7 @@ void run_reencode(artalk_model* m, int B, hipStream_t s) {
     const artalk_config& c = m->cfg;
     Workspace& w = m->view ? *m->view : m->ws;
     const int H = c.vae_hidden, T = 100;
+    Range r_re("artalk.vae.reencode_bsq");              // K16-K17: encoder, multi-scale BSQ, history features
     linear(m, w.enc_in, 128, m->enc.in_w, m->enc.in_b, w.vh, H, B * T, H, 128, ACT_LEAKY02, nullptr, s);
     run_vae_stack(m, m->enc, B, T, 0, s);
     linear(m, w.vh, H, m->enc.out_w, m->enc.out_b, w.enc_out, c.code_dim, B * T, c.code_dim, H, ACT_NONE, nullptr, s, LF_EXACT);
@@ -569,6 +588,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
     // format by their producers, which lets every block GEMM use the LDS-DMA kernels (gemm_p8_sm_kernel at these grid sizes)
     const int p8 = m->precision == 1 ? 1 : 0;
     // K/V of the 181 history tokens, once per layer (raw prev tokens, not modulated: app/transformer.py:68-70)
+    roctxRangePushA("artalk.ar.history_kv");
     if (p8) launch_pack_split(w.prev_in, reinterpret_cast<unsigned int*>(w.prev_in_p8), (long)B * kNTok * kE, false, s);   // one split for the 12 layers
     for (int l = 0; l < c.ar_depth; ++l) {
         const ARLayer& L = m->ar[l];
@@ -579,8 +599,12 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
         g.M = B * kNTok; g.N = 2 * kE; g.K = kE;
         gemm(m, g, s);
     }
+    roctxRangePop();
     launch_ar_begin(w.style_cond, m->lvl_pos, w.x, w.fhat, B, s);
+    static const char* const kLevelName[kMaxLv] = {"artalk.ar.scale_step0", "artalk.ar.scale_step1", "artalk.ar.scale_step2",
+                                                   "artalk.ar.scale_step3", "artalk.ar.scale_step4"};
     for (int p = 0; p < c.n_levels; ++p) {
+        Range r_lv(kLevelName[p]);                       // K8-K14 of one scale step: 12 blocks, head, bits, next-scale features
         const int pn = m->pn[p], off = m->off[p], M = B * pn;
         const RowMap amap = rowmap(pn, kNTok, off);            // rows of the AdaLN table for this level's tokens
         for (int l = 0; l < c.ar_depth; ++l) {
@@ -630,11 +654,13 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
     stage_mark(m, s, PB_AR);
     // ---- VAE decode of [history | current] (bitwise_vae.py:105-113) ----
     const int H = c.vae_hidden;
+    roctxRangePushA("artalk.vae.decode");               // K15
     launch_dec_input(w.prev_fdec, w.fhat, w.bits, m->dec_pos, w.dec_x, B, s);
     linear(m, w.dec_x, c.code_dim, m->dec.in_w, m->dec.in_b, w.vh, H, B * 200, H, c.code_dim, ACT_LEAKY02, nullptr, s);
     run_vae_stack(m, m->dec, B, 200, 100, s);
     linear(m, w.vh, H, m->dec.out_w, m->dec.out_b, w.dec_out, c.motion_dim, B * 200, c.motion_dim, H, ACT_NONE, nullptr, s);
     launch_dec_finish(w.dec_out, m->vae_mean, m->vae_std, m->enc_pos, w.motion_chunk, 100L * c.motion_dim, 0, w.enc_in, B, s, w.status);
+    roctxRangePop();
     // ---- re-encode the generated motion into the next history (app/models.py:111-114) ----
     run_reencode(m, B, s);
     stage_mark(m, s, PB_VAE);
@@ -1151,10 +1177,13 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
         const int Bn = Bj[j];
         if (overlap) HIPCHK(m, hipStreamWaitEvent(s, m->w2v_done[j], 0));
         // AdaLN table of this chunk index for all blocks + head: SiLU(cond) @ [W_0;...;W_11;W_head]^T
+        roctxRangePushA("artalk.ar.adaln_table");
         linear(m, w.silu_cond + (long)base[j] * kNTok * kCond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, Bn * kNTok, m->ada_n, kCond,
                ACT_NONE, nullptr, s, m->precision == 1 ? LF_A_P8 : 0);
         stage_mark(m, s, PB_ADA);
+        roctxRangePop();
         if (graphs) {
+            Range r_body("artalk.body.graph");
             if (int brc = run_chunk_body_graphs(m, Bn, s)) return brc;
             stage_mark(m, s, PB_AR);   // light profiling: the whole captured body (AR steps + VAE) is charged to the AR bucket
         } else {
