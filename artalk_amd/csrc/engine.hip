@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -104,6 +105,7 @@ struct artalk_model {
     std::vector<PackRange> wranges;   // every weight allocation and its packed f16x3 copy (built at finalize)
     int precision = 0;                // 0: fp32 MFMA everywhere, 1: f16x3 split GEMMs (heads stay fp32)
     int splitk_tiles = 192, splitk_target = 384;   // split-K when the grid has fewer tiles than splitk_tiles; aim at splitk_target workgroups
+    int sm_split_768 = 1;             // tuning (ARTALK_SM_SPLIT768): split K = 768 GEMMs of the smallest scale steps too (deep-ring kernels)
     int stream_B = 0;                 // streams opened by artalk_stream_begin (history lives in the workspace)
     Workspace* view = nullptr;        // workspace view (clip sub-range) the body launchers currently work on; null = m->ws
     bool sticky_error = false;        // set by internal consistency checks inside the launch sequence; reported by artalk_infer
@@ -374,7 +376,10 @@ void stage_mark(artalk_model* m, hipStream_t s, int bucket) {
     ((m->w2v_stream && s == m->w2v_stream) ? m->marks_w2v : m->marks).emplace_back(bucket, i);
 }
 
-void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
+// fuse_ln: the AdaLN-modulated LayerNorm that consumes this GEMM's (768-wide, residual-stream) result.  If the GEMM is split
+// over K, its reduce pass also writes that LayerNorm's output (one launch instead of two) and gemm() returns true; otherwise
+// the caller launches the LayerNorm itself.
+bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse_ln = nullptr) {
     GemmArgs g = g0;
     g.graph_tag = m->in_body ? 1 : 0;
     bool split = false;
@@ -389,12 +394,24 @@ void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
         const int tiles = gemm_tile_count(g, split);
         const int lim = m->splitk_tiles, tgt = m->splitk_target;
         if (sm_path) {
-            // gemm_p8_sm_kernel keeps 3 K tiles in flight, so a K = 768 tile takes ~9 us and splitting it only adds the reduce pass
-            // (proj at M = 800: 9.4 us unsplit, 13.1 split in 2); K = 3072 still gains below ~192 tiles (16.0 vs 26.5 us at M = 400)
-            // (profiles/r01_gemm_f16s_bench.log)
-            int S = (g.K >= 2048 && tiles < 192) ? (tiles < 48 ? 6 : 3) : 1;
-            while (S > 1 && (int64_t)S * g.M * g.N > cw.splitk_floats) --S;
-            if (S > 1) { g.splitk = S; g.partial = cw.splitk; }
+            // Small-grid LDS-DMA kernel (64x64 tiles).  These launches are latency-bound: measured with cold weights, replayed from a
+            // graph, GEMM + reduce (profiles/r02_tiny_gemm_sweep.log): K = 3072 gains from a split below ~192 tiles (M = 400: 19.1 us
+            // split in 6 vs 27 unsplit); K = 768 gains only on the smallest grids, where the split workgroups' whole K slice fits the
+            // ring and is in flight at once (deep-ring configurations 23 / 24): proj at M = 80 7.8 us split in 6 vs 9.8, qkv 9.9 us
+            // split in 3 vs 13.2.  A split 768-wide result also gets its LayerNorm for free (fuse_ln).
+            int S = 1, cfg = -1;
+            if (g.K >= 2048) {
+                if (tiles <= 24) { S = 8; cfg = 23; }
+                else if (tiles < 192) S = tiles < 48 ? 6 : 3;
+            } else if (m->sm_split_768) {
+                if (tiles <= 24) { S = 6; cfg = 24; }
+                else if (tiles <= 36) { S = 4; cfg = 24; }
+                else if (tiles <= 72) { S = 3; cfg = 23; }
+                else if (tiles <= 108) S = 2;
+            }
+            while (S > 1 && (int64_t)S * g.M * g.N > cw.splitk_floats) { --S; cfg = -1; }
+            if (S == 5 || S == 7) { --S; }        // the unrolled reduce kernels exist for 2, 3, 4, 6, 8 slabs
+            if (S > 1) { g.splitk = S; g.partial = cw.splitk; if (g.force_cfg < 0) g.force_cfg = cfg; }
         } else if (tiles < lim) {
             int S = std::min(std::min(g.K / 64, (tgt + tiles - 1) / tiles), 16);
             while (S > 1 && (int64_t)S * g.M * g.N > cw.splitk_floats) --S;
@@ -405,17 +422,22 @@ void gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s) {
                           (split ? (g.a_packed ? (gemm_p8_eligible(g) && gemm_p8_variant(g) == 0) : gemm_f16s_config(g) == 0) : gemm_config(g) == 4);
     size_t i0 = 0, i1 = 0;
     if (m->profiling && dominant) next_event(m, s, &i0);
-    if (g.a_packed && !split) { m->err = "internal: P8 activation handed to an fp32 GEMM"; m->sticky_error = true; return; }
+    if (g.a_packed && !split) { m->err = "internal: P8 activation handed to an fp32 GEMM"; m->sticky_error = true; return false; }
     const bool dma = split && g.splitk == 1 && gemm_p8_eligible(g);
     if (dma) launch_gemm_p8(g, s);
     else if (split && gemm_p8_sm_eligible(g)) launch_gemm_p8_sm(g, s);     // P8 activation, small grid (AR/VAE scale steps)
     else if (split) launch_gemm_f16s(g, s);
     else launch_gemm(g, s);
-    if (g.splitk > 1) launch_splitk_reduce(g, s);
+    bool fused = false;
+    if (g.splitk > 1) {
+        if (fuse_ln && splitk_reduce_ln_eligible(g, *fuse_ln)) { launch_splitk_reduce_ln(g, *fuse_ln, s); fused = true; }
+        else launch_splitk_reduce(g, s);
+    }
     if (m->profiling && dominant) {
         next_event(m, s, &i1);
         m->dom_events.emplace_back(i0, gemm_flops(g));
     }
+    return fused;
 }
 
 enum { LF_EXACT = 1, LF_A_P8 = 2, LF_C_P8 = 4 };   // linear() flags: decision-critical (fp32 path) / A is in P8 / write C in P8
@@ -607,14 +629,26 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
         Range r_lv(kLevelName[p]);                       // K8-K14 of one scale step: 12 blocks, head, bits, next-scale features
         const int pn = m->pn[p], off = m->off[p], M = B * pn;
         const RowMap amap = rowmap(pn, kNTok, off);            // rows of the AdaLN table for this level's tokens
+        // AdaLN-modulated LayerNorm into w.xmod: block l's first (which = 0) / second (1) norm, or the head's (l = depth).  Each is
+        // either its own launch or - when the GEMM that produces x is split over K - written by that GEMM's reduce pass.
+        auto ln_args = [&](int l, int which) {
+            LnArgs n;
+            n.X = w.x; n.ldx = kE; n.Y = w.xmod; n.ldy = kE; n.ldm = ldada; n.mmap = amap; n.M = M; n.D = kE; n.eps = 1e-6f;
+            if (l < c.ar_depth) {
+                const float* ada = w.ada + (long)l * 6 * kE;   // gamma1,gamma2,scale1,scale2,shift1,shift2 (app/transformer.py:32)
+                n.scale = ada + (2 + which) * kE; n.shift = ada + (4 + which) * kE; n.out_p8 = p8;
+            } else {                                           // head (app/models.py:145-148): scale, shift = split2; fp32 (exact logits GEMM)
+                const float* hada = w.ada + (long)c.ar_depth * 6 * kE;
+                n.scale = hada; n.shift = hada + kE; n.out_p8 = 0;
+            }
+            return n;
+        };
+        bool have_ln = false;                                  // w.xmod already holds the norm the next GEMM reads
         for (int l = 0; l < c.ar_depth; ++l) {
             const ARLayer& L = m->ar[l];
-            const float* ada = w.ada + (long)l * 6 * kE;       // gamma1,gamma2,scale1,scale2,shift1,shift2 (app/transformer.py:32)
+            const float* ada = w.ada + (long)l * 6 * kE;
             float* cache = w.cache + l * cache_l;
-            LnArgs n1;
-            n1.X = w.x; n1.ldx = kE; n1.Y = w.xmod; n1.ldy = kE; n1.scale = ada + 2 * kE; n1.shift = ada + 4 * kE; n1.ldm = ldada;
-            n1.mmap = amap; n1.M = M; n1.D = kE; n1.eps = 1e-6f; n1.out_p8 = p8;
-            launch_layernorm(n1, s);
+            if (!have_ln) launch_layernorm(ln_args(l, 0), s);
             GemmArgs q;
             q.A = w.xmod; q.lda = kE; q.W = L.qkv_w; q.ldw = kE; q.bias = L.qkv_b; q.C = cache; q.ldc = 3 * kE;
             q.cmap = rowmap(pn, 2 * kNTok, kNTok + off); q.M = M; q.N = 3 * kE; q.K = kE; q.a_packed = p8;
@@ -629,22 +663,16 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
             GemmArgs pj;
             pj.A = w.attn_out; pj.lda = kE; pj.W = L.proj_w; pj.ldw = kE; pj.bias = L.proj_b; pj.C = w.x; pj.ldc = kE;
             pj.gate = ada; pj.ldg = ldada; pj.gmap = amap; pj.R = w.x; pj.ldr = kE; pj.M = M; pj.N = kE; pj.K = kE; pj.a_packed = p8;
-            gemm(m, pj, s);
-            LnArgs n2 = n1;
-            n2.scale = ada + 3 * kE; n2.shift = ada + 5 * kE;
-            launch_layernorm(n2, s);
+            const LnArgs n2 = ln_args(l, 1);
+            if (!gemm(m, pj, s, &n2)) launch_layernorm(n2, s);
             linear(m, w.xmod, kE, L.ffn1_w, L.ffn1_b, w.ffn_h, 4 * kE, M, 4 * kE, kE, ACT_GELU_TANH, nullptr, s, p8 ? (LF_A_P8 | LF_C_P8) : 0);
             GemmArgs f2;
             f2.A = w.ffn_h; f2.lda = 4 * kE; f2.W = L.ffn2_w; f2.ldw = 4 * kE; f2.bias = L.ffn2_b; f2.C = w.x; f2.ldc = kE;
             f2.gate = ada + kE; f2.ldg = ldada; f2.gmap = amap; f2.R = w.x; f2.ldr = kE; f2.M = M; f2.N = kE; f2.K = 4 * kE; f2.a_packed = p8;
-            gemm(m, f2, s);
+            const LnArgs nn = ln_args(l + 1, 0);               // next block's first norm, or the head's after the last block
+            have_ln = gemm(m, f2, s, &nn);
         }
-        // head (app/models.py:145-148,103): scale, shift = split2
-        const float* hada = w.ada + (long)c.ar_depth * 6 * kE;
-        LnArgs nh;
-        nh.X = w.x; nh.ldx = kE; nh.Y = w.xmod; nh.ldy = kE; nh.scale = hada; nh.shift = hada + kE; nh.ldm = ldada; nh.mmap = amap;
-        nh.M = M; nh.D = kE; nh.eps = 1e-6f;
-        launch_layernorm(nh, s);
+        if (!have_ln) launch_layernorm(ln_args(c.ar_depth, 0), s);
         linear(m, w.xmod, kE, m->logits_w, m->logits_b, w.logits, 2 * c.code_dim, M, 2 * c.code_dim, kE, ACT_NONE, nullptr, s, LF_EXACT);
         launch_ar_bits_next(w.logits, w.bits, w.fhat, w.nextfeat, B, p, s, w.status);
         if (p + 1 < c.n_levels)
@@ -875,6 +903,7 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return ARTALK_EHIP; }
     artalk_model* m = new artalk_model();
     m->cfg = c; m->device = device_id;
+    if (const char* e = getenv("ARTALK_SM_SPLIT768")) m->sm_split_768 = atoi(e);
     // conv stack geometry: T_l valid frames; row stride S_l per chunk with S_l = 2*S_{l+1} so that one GEMM covers all chunks
     int T = kSamplesPerChunk;
     for (int i = 0; i < c.w2v_n_conv; ++i) { T = (T - c.w2v_conv_kernel[i]) / c.w2v_conv_stride[i] + 1; m->conv_T[i] = T; }
@@ -1415,7 +1444,7 @@ int artalk_op_pack_split(const float* in, void* out_u32, int64_t n, int is_weigh
 }
 int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const void* Wp, const float* bias, float* C, int M, int N,
                                int K, int act, int force_cfg, void* stream) {
-    if (!A || !Wp || !C || K % 32 != 0 || M <= 32 || N <= 0) return ARTALK_EINVAL;
+    if (!A || !Wp || !C || K % 32 != 0 || M <= 0 || N <= 0 || (M <= 32 && (force_cfg & 0xff) < 20)) return ARTALK_EINVAL;
     GemmArgs g;
     g.A = (const float*)A; g.a_packed = a_packed; g.lda = lda; g.W = nullptr; g.Wp = (const unsigned int*)Wp; g.ldw = K; g.bias = bias;
     g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act; g.force_cfg = force_cfg;

@@ -239,7 +239,12 @@ __device__ __forceinline__ f16x8 lds_read128(unsigned addr) {
 }
 template <int UNIT>
 __device__ __forceinline__ void wait_vmcnt_units(int units) {   // at most `units` groups of UNIT DMA instructions stay in flight
-    if (units >= 3) wait_vmcnt<3 * UNIT>();
+    static_assert(7 * UNIT <= 63, "vmcnt is a 6-bit counter");
+    if (units >= 7) wait_vmcnt<7 * UNIT>();
+    else if (units == 6) wait_vmcnt<6 * UNIT>();
+    else if (units == 5) wait_vmcnt<5 * UNIT>();
+    else if (units == 4) wait_vmcnt<4 * UNIT>();
+    else if (units == 3) wait_vmcnt<3 * UNIT>();
     else if (units == 2) wait_vmcnt<2 * UNIT>();
     else if (units == 1) wait_vmcnt<UNIT>();
     else wait_vmcnt<0>();
@@ -1226,12 +1231,19 @@ static void launch_p8_sm_cfg(const GemmArgs& g, hipStream_t s) {
 bool gemm_p8_sm_eligible(const GemmArgs& g) {
     return g.Wp != nullptr && g.a_packed && g.amode == 0 && g.batch == 1 && g.K % 32 == 0 && (g.lda % 8) == 0;
 }
-// force_cfg 20: 64x64 x 4 stages (default), 21: 128x64 x 3 stages, 22: 128x128 x 3 stages
+// force_cfg 20: 64x64 x 4 stages (default), 21: 128x64 x 3 stages, 22: 128x128 x 3 stages; deep rings for the split-K launches of
+// the small scale steps, where a workgroup's whole K slice should be in flight at once (the launch then costs one memory
+// latency instead of one per K step): 23: 64x64 x 8 stages (128 KiB, one workgroup per CU), 24: 64x64 x 5 stages (80 KiB, two
+// per CU), 25: 64x128 x 5 stages (120 KiB), 26: 128x64 x 5 stages (120 KiB)
 void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return;
     switch (g.force_cfg) {
         case 21: launch_p8_sm_cfg<128, 64, 3>(g, s); break;
         case 22: launch_p8_sm_cfg<128, 128, 3>(g, s); break;
+        case 23: launch_p8_sm_cfg<64, 64, 8>(g, s); break;
+        case 24: launch_p8_sm_cfg<64, 64, 5>(g, s); break;
+        case 25: launch_p8_sm_cfg<64, 128, 5>(g, s); break;
+        case 26: launch_p8_sm_cfg<128, 64, 5>(g, s); break;
         default: launch_p8_sm_cfg<64, 64, 4>(g, s); break;
     }
 }

@@ -205,6 +205,10 @@ void launch_gemm(const GemmArgs& g, hipStream_t s) {
 
 // ---- split-K epilogue pass: C = R + gate * act(sum_y partial[y] + bias), partials added in y order (deterministic)
 namespace artalk {
+// S is a compile-time constant (1..8; 0 = run-time loop for deeper splits) so that the S slab loads of an element are all issued
+// before the first add: the slabs were written a moment ago by workgroups on other XCDs, every load is an L2 miss, and a
+// run-time loop paid those latencies one after the other (5 us for a 20-row reduce).
+template <int S>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
     const long total = (long)g.M * g.N;
     const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
@@ -212,7 +216,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
         for (long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 4; idx < total; idx += (long)gridDim.x * 1024) {
             const int row = (int)(idx / g.N), col0 = (int)(idx - (long)row * g.N);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            for (int y = 0; y < g.splitk; ++y) v += *reinterpret_cast<const f32x4*>(g.partial + (long)y * total + idx);
+            if (S > 0) {
+                f32x4 t[S > 0 ? S : 1];
+#pragma unroll
+                for (int y = 0; y < S; ++y) t[y] = *reinterpret_cast<const f32x4*>(g.partial + (long)y * total + idx);
+#pragma unroll
+                for (int y = 0; y < S; ++y) v += t[y];
+            } else {
+                for (int y = 0; y < g.splitk; ++y) v += *reinterpret_cast<const f32x4*>(g.partial + (long)y * total + idx);
+            }
             epilogue_row4(g, epi, row, col0, v);
         }
         return;
@@ -240,7 +252,97 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
 void launch_splitk_reduce(const GemmArgs& g, hipStream_t s) {
     const long total = (long)g.M * g.N;
     const long blocks = (total / 4 + 255) / 256;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048)), dim3(256), 0, s, g);
+    const dim3 grid((unsigned)(blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048));
+    switch (g.splitk) {
+        case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, grid, dim3(256), 0, s, g); break;
+        case 3: hipLaunchKernelGGL(splitk_reduce_kernel<3>, grid, dim3(256), 0, s, g); break;
+        case 4: hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, s, g); break;
+        case 6: hipLaunchKernelGGL(splitk_reduce_kernel<6>, grid, dim3(256), 0, s, g); break;
+        case 8: hipLaunchKernelGGL(splitk_reduce_kernel<8>, grid, dim3(256), 0, s, g); break;
+        default: hipLaunchKernelGGL(splitk_reduce_kernel<0>, grid, dim3(256), 0, s, g); break;
+    }
+}
+
+// The same pass for a GEMM whose result is the 768-wide residual stream x of an AR block and is followed by the AdaLN-modulated
+// LayerNorm of the next GEMM's input (app/transformer.py:35,40; app/models.py:148): one wavefront per row sums the slabs, applies
+// bias / gate / residual, writes x, and - still holding the row in registers - writes LN(x) * (1 + scale) + shift for the consumer
+// (P8 or fp32).  Replaces splitk_reduce + layernorm (two launches, one extra trip of x through memory) on the small scale steps.
+template <int S>
+__global__ __launch_bounds__(256) void splitk_reduce_ln768_kernel(const GemmArgs g, const LnArgs ln) {
+    constexpr int D = 768, NA = 3;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= g.M) return;
+    const long total = (long)g.M * D;
+    const long crow = map_row(g.cmap, row);
+    const float* gp = g.gate ? g.gate + (long)map_row(g.gmap, row) * g.ldg : nullptr;
+    const long mr = map_row(ln.mmap, row);
+    const float* sc = ln.scale + mr * ln.ldm;
+    const float* sh = ln.shift + mr * ln.ldm;
+    f32x4 t[NA][S], bv[NA], gv[NA], rv[NA], scv[NA], shv[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = (i * 64 + lane) * 4;
+#pragma unroll
+        for (int y = 0; y < S; ++y) t[i][y] = *reinterpret_cast<const f32x4*>(g.partial + (long)y * total + (long)row * D + c);
+        bv[i] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        gv[i] = gp ? *reinterpret_cast<const f32x4*>(gp + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+        rv[i] = g.R ? *reinterpret_cast<const f32x4*>(g.R + crow * g.ldr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        scv[i] = *reinterpret_cast<const f32x4*>(sc + c);
+        shv[i] = *reinterpret_cast<const f32x4*>(sh + c);
+    }
+    float v[NA][4];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int y = 0; y < S; ++y) a += t[i][y];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = apply_act_rt(a[e] + bv[i][e], g.act);
+            if (g.gate) x *= gv[i][e];
+            v[i][e] = x + rv[i][e];
+            s1 += v[i][e];
+        }
+        const f32x4 o = {v[i][0], v[i][1], v[i][2], v[i][3]};
+        *reinterpret_cast<f32x4*>(g.C + crow * g.ldc + (i * 64 + lane) * 4) = o;
+    }
+    // same arithmetic as layernorm_kernel<768> (norm.hip)
+    const float mean = wave_sum(s1) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + ln.eps);
+    float* y = ln.Y + (long)row * ln.ldy;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * (scv[i][e] + 1.0f) + shv[i][e];
+        if (ln.out_p8) store_p8x4_pair(y, c, o[0], o[1], o[2], o[3]);
+        else { const f32x4 w = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4*>(y + c) = w; }
+    }
+}
+bool splitk_reduce_ln_eligible(const GemmArgs& g, const LnArgs& ln) {
+    const int S = g.splitk;
+    auto al16 = [](const void* p) { return ((unsigned long long)p & 15) == 0; };
+    return g.N == 768 && ln.D == 768 && ln.M == g.M && (S == 2 || S == 3 || S == 4 || S == 6 || S == 8) && ln.scale && ln.shift && !ln.w &&
+           ln.act == ACT_NONE && g.c_p8 == 0 && (g.ldc % 4) == 0 && (g.ldr % 4) == 0 && (g.ldg % 4) == 0 && (ln.ldm % 4) == 0 && (ln.ldy % 8) == 0 &&
+           al16(g.partial) && al16(g.C) && al16(g.R) && al16(g.gate) && al16(g.bias) && al16(ln.scale) && al16(ln.shift) && al16(ln.Y);
+}
+void launch_splitk_reduce_ln(const GemmArgs& g, const LnArgs& ln, hipStream_t s) {
+    const dim3 grid((g.M + 3) / 4);
+    switch (g.splitk) {
+        case 2: hipLaunchKernelGGL(splitk_reduce_ln768_kernel<2>, grid, dim3(256), 0, s, g, ln); break;
+        case 3: hipLaunchKernelGGL(splitk_reduce_ln768_kernel<3>, grid, dim3(256), 0, s, g, ln); break;
+        case 4: hipLaunchKernelGGL(splitk_reduce_ln768_kernel<4>, grid, dim3(256), 0, s, g, ln); break;
+        case 6: hipLaunchKernelGGL(splitk_reduce_ln768_kernel<6>, grid, dim3(256), 0, s, g, ln); break;
+        default: hipLaunchKernelGGL(splitk_reduce_ln768_kernel<8>, grid, dim3(256), 0, s, g, ln); break;
+    }
 }
 int gemm_tile_count(const GemmArgs& g, bool f16s) {
     int bm, bn;

@@ -50,6 +50,10 @@ struct GemmArgs {
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);
 void launch_splitk_reduce(const GemmArgs& g, hipStream_t s);   // epilogue pass of a split-K GEMM (g.splitk > 1)
+struct LnArgs;
+// split-K epilogue pass fused with the AdaLN-modulated LayerNorm that consumes the 768-wide result (AR residual stream)
+bool splitk_reduce_ln_eligible(const GemmArgs& g, const LnArgs& ln);
+void launch_splitk_reduce_ln(const GemmArgs& g, const LnArgs& ln, hipStream_t s);
 int gemm_tile_count(const GemmArgs& g, bool f16s);             // output tiles of the configuration launch_gemm[_f16s] would pick
 // fp32-accurate GEMM on the fp16 matrix cores by operand splitting (gemm_f16s.hip)
 void launch_pack_split(const float* w, unsigned int* out, long n, bool is_weight, hipStream_t s);

@@ -14,11 +14,20 @@ SHAPES = [("w2v qkv", 19200, 3072, 1024), ("w2v out", 19200, 1024, 1024), ("w2v 
           ("g qkv p3", 800, 2304, 768), ("g proj p3", 800, 768, 768), ("g ffn1 p3", 800, 3072, 768), ("g ffn2 p3", 800, 768, 3072),
           ("g qkv p2", 400, 2304, 768), ("g proj p2", 400, 768, 768), ("g ffn1 p2", 400, 3072, 768), ("g ffn2 p2", 400, 768, 3072),
           ("g qkv p1", 80, 2304, 768), ("g ffn2 p1", 80, 768, 3072), ("g hist kv", 2896, 1536, 768)]
+# the four GEMMs of an AR block at every row count a scale step can have: "t<M> qkv|proj|ffn1|ffn2"
+for _M in (16, 32, 80, 160, 400, 800, 1600, 3200):
+    SHAPES += [(f"t{_M} qkv", _M, 2304, 768), (f"t{_M} proj", _M, 768, 768), (f"t{_M} ffn1", _M, 3072, 768), (f"t{_M} ffn2", _M, 768, 3072)]
+# row counts whose 128x128 tile counts are whole multiples of the 512 persistent workgroups (round-quantisation check)
+for _M in (8192, 16384):
+    SHAPES += [(f"q{_M} qkv", _M, 3072, 1024), (f"q{_M} out", _M, 1024, 1024), (f"q{_M} ff1", _M, 4096, 1024), (f"q{_M} ff2", _M, 1024, 4096)]
 variants = [(1, 1), (2, 1), (7, 1), (8, 1)]   # (cfg, A packed): 0/1 register-staged 128x128 / 64x64; LDS-DMA kernels: 2 128x128, 6 256x128, 7 256x256,
                                                # 8 two-workgroup 128x128, 20/21/22 small-grid 64x64 / 128x64 / 128x128; cfg | S << 8 = split-K S (8, 20-22)
 only = os.environ.get("GEMM_ONLY")
 if only:
-    SHAPES = [x for x in SHAPES if x[0] in only.split(",")]
+    SHAPES = [x for x in SHAPES if x[0] in only.split(",") or any(o.endswith("*") and x[0].startswith(o[:-1]) for o in only.split(","))]
+# GEMM_ROTATE=n: cycle through n copies of the weight matrix, so that (as in the model, whose 12 blocks hold 340 MB of split
+# weights) a launch does not find its weights in L2 / Infinity Cache from the previous launch
+ROT = int(os.environ.get("GEMM_ROTATE", "1"))
 if os.environ.get("GEMM_VARIANTS"):
     variants = [tuple(int(v) for v in x.split(":")) for x in os.environ["GEMM_VARIANTS"].split(",")]
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -26,20 +35,33 @@ for name, M, N, K in SHAPES:
     A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.03; b = torch.randn(N, device="cuda")
     Ap = torch.empty(M, K, dtype=torch.int32, device="cuda"); Wp = torch.empty(N, K, dtype=torch.int32, device="cuda")
     L.artalk_op_pack_split(p(A), p(Ap), M * K, 0, s); L.artalk_op_pack_split(p(W), p(Wp), N * K, 1, s)
+    Wps = [Wp] + [Wp.clone() for _ in range(ROT - 1)]
     Cc = torch.empty(M, N, device="cuda")
     ref = A[:256].double() @ W.double().t() + b.double()
     line = f"{name:12s} M={M:6d} N={N:5d} K={K:4d} "
     for cfg, apk in variants:
         if 2 <= (cfg & 0xff) < 20 and (cfg & 0xff) != 8 and M < 3000: continue
         best = 1e9
-        n = 3 if M * N * K > 1e11 else 10
+        n = 3 if M * N * K > 1e11 else (10 if ROT == 1 else ROT)
+        a = Ap if apk else A
+        L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wp), p(b), p(Cc), M, N, K, 0, cfg, s)      # warm-up (allocates the split-K scratch)
+        torch.cuda.synchronize()
+        graph = None
+        if os.environ.get("GEMM_GRAPH", "1") == "1" and M * N * K < 1e11:
+            # the launches replayed from a hipGraph, as the model runs them: eager launches are host-bound below ~3.5 us per kernel
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                for it in range(n):
+                    L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wps[it % ROT]), p(b), p(Cc), M, N, K, 0, cfg, gs)
         for rnd in range(3):
-            a = Ap if apk else A
-            L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wp), p(b), p(Cc), M, N, K, 0, cfg, s)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(n):
-                L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wp), p(b), p(Cc), M, N, K, 0, cfg, s)
+            if graph is not None:
+                graph.replay()
+            else:
+                for it in range(n):
+                    L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wps[it % ROT]), p(b), p(Cc), M, N, K, 0, cfg, s)
             e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / n)
         err = float((Cc[:256].double() - ref).abs().max() / ref.abs().max())

@@ -4,6 +4,7 @@
   summarize_profile.py stats  <dir> <out.csv>            kernel-trace --stats: the per-kernel table
   summarize_profile.py pmc    <fetch_dir> <write_dir> <out.json>   FETCH_SIZE / WRITE_SIZE passes -> bytes per launch
   summarize_profile.py shapes <dir> <out.csv>            kernel-trace: time per (kernel, grid size), the launch-shape view
+  summarize_profile.py levels <dir> <out.csv>            kernel-trace of a --branches 1 run: the AR/VAE body per scale step
 
 HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
 exactly half of a wide (16 B/lane) coalesced read stream, so reads = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact.
@@ -51,6 +52,70 @@ def shapes(d, out):
     print(open(out).read())
 
 
+def levels(d, out):
+    """Kernel trace of a run with ONE clip group (bench.py --branches 1): the AR/VAE body of a chunk index is a fixed kernel
+    sequence; cut it at ar_begin / ar_bits / dec_input / bsq_history and report, per segment, the summed kernel time, the wall
+    span (first start to last end) and the launches, averaged over the bodies of the trace, plus the top kernels per segment."""
+    rows = [r for r in csv.DictReader(open(find(d, "*kernel_trace.csv")))]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    seg_names = ["hist_kv", "level0", "level1", "level2", "level3", "level4", "vae_decode", "reencode"]
+    segs = {n: dict(kernel_us=0.0, wall_us=0.0, launches=0, n=0, kern=collections.defaultdict(lambda: [0, 0.0])) for n in seg_names}
+    cur, lvl, start, last_end, bodies = None, 0, None, None, 0
+    pending = []     # launches since the last boundary that may belong to hist_kv (they precede ar_begin)
+
+    def close(name, items):
+        if not items:
+            return
+        sg = segs[name]
+        sg["n"] += 1
+        sg["launches"] += len(items)
+        sg["wall_us"] += (max(int(r["End_Timestamp"]) for r in items) - min(int(r["Start_Timestamp"]) for r in items)) / 1e3
+        for r in items:
+            dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            sg["kernel_us"] += dur
+            k = sg["kern"][short(r["Kernel_Name"])]
+            k[0] += 1
+            k[1] += dur
+
+    items = []
+    state = "outside"
+    for r in rows:
+        name = short(r["Kernel_Name"])
+        if state == "outside":
+            # the history K/V GEMMs (12 launches + a pack) directly precede ar_begin: keep a short window
+            if name.startswith("ar_begin_kernel"):
+                close("hist_kv", pending[-13:])
+                pending = []
+                state, lvl, items = "level", 0, [r]
+                bodies += 1
+            else:
+                pending.append(r)
+            continue
+        items.append(r)
+        if state == "level" and name.startswith("ar_bits_kernel"):
+            close(f"level{lvl}", items)
+            items = []
+            lvl += 1
+            if lvl == 5:
+                state = "vae"
+        elif state == "vae" and name.startswith("dec_finish_kernel"):
+            close("vae_decode", items)
+            items, state = [], "reenc"
+        elif state == "reenc" and name.startswith("vq_embed_kernel"):
+            close("reencode", items)
+            items, state, pending = [], "outside", []
+    with open(out, "w") as f:
+        f.write("segment,bodies,launches_per_body,kernel_us_per_body,wall_us_per_body,top_kernels(us per body)\n")
+        for n in seg_names:
+            sg = segs[n]
+            if not sg["n"]:
+                continue
+            top = sorted(sg["kern"].items(), key=lambda t: -t[1][1])[:6]
+            tops = "; ".join(f"{k} x{v[0] // sg['n']} {v[1] / sg['n']:.0f}" for k, v in top)
+            f.write(f"{n},{sg['n']},{sg['launches'] / sg['n']:.0f},{sg['kernel_us'] / sg['n']:.0f},{sg['wall_us'] / sg['n']:.0f},\"{tops}\"\n")
+    print(open(out).read())
+
+
 def pmc(fd, wd, out):
     res = collections.defaultdict(dict)
     for tag, d in (("FETCH_SIZE", fd), ("WRITE_SIZE", wd)):
@@ -78,7 +143,9 @@ def pmc(fd, wd, out):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "shapes":
+    if sys.argv[1] == "levels":
+        levels(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "shapes":
         shapes(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
