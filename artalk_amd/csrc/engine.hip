@@ -105,6 +105,7 @@ struct artalk_model {
     std::vector<PackRange> wranges;   // every weight allocation and its packed f16x3 copy (built at finalize)
     int precision = 0;                // 0: fp32 MFMA everywhere, 1: f16x3 split GEMMs (heads stay fp32)
     int splitk_tiles = 192, splitk_target = 384;   // split-K when the grid has fewer tiles than splitk_tiles; aim at splitk_target workgroups
+    int hist_kv_batched = 1;          // tuning (ARTALK_HIST_KV_BATCHED): history K/V of all blocks as one GEMM over column groups
     int sm_split_768 = 1;             // tuning (ARTALK_SM_SPLIT768): split K = 768 GEMMs of the smallest scale steps too (deep-ring kernels)
     int stream_B = 0;                 // streams opened by artalk_stream_begin (history lives in the workspace)
     Workspace* view = nullptr;        // workspace view (clip sub-range) the body launchers currently work on; null = m->ws
@@ -120,6 +121,7 @@ struct artalk_model {
     float *pos_w = nullptr, *pos_b = nullptr, *enc_lnw = nullptr, *enc_lnb = nullptr;
     std::vector<W2VLayer> w2v;
     float *ada_w = nullptr, *ada_b = nullptr;
+    float *ar_qkv_w = nullptr, *ar_qkv_b = nullptr;   // [depth][3E][E] / [depth][3E]: every block's q|k|v weights, contiguous
     std::vector<ARLayer> ar;
     float *logits_w = nullptr, *logits_b = nullptr, *vq_w = nullptr, *vq_b = nullptr, *sc_w = nullptr, *sc_b = nullptr;
     float *null_style = nullptr, *lvl_pos = nullptr, *prev_lvl_pos = nullptr;
@@ -241,13 +243,17 @@ int build_registry(artalk_model* m) {
     add_slot(m, "cond_logits_head.ada_lin.1.weight", {2 * kE, kCond}, SK_DIRECT, m->ada_w + (int64_t)c.ar_depth * 6 * kE * kCond);
     add_slot(m, "cond_logits_head.ada_lin.1.bias", {2 * kE}, SK_DIRECT, m->ada_b + c.ar_depth * 6 * kE);
     m->ar.resize(c.ar_depth);
+    // q|k|v weights of all blocks in ONE allocation ([depth][3E][E]): the K/V projections of the 181 history tokens are the same
+    // input through every block's key / value weights, and run as one GEMM over column groups (run_chunk_body)
+    m->ar_qkv_w = walloc(m, (int64_t)c.ar_depth * 3 * kE * kE);
+    m->ar_qkv_b = walloc(m, (int64_t)c.ar_depth * 3 * kE);
     for (int i = 0; i < c.ar_depth; ++i) {
         ARLayer& L = m->ar[i];
         const std::string p = "attn_blocks." + std::to_string(i);
         add_slot(m, p + ".attn.scale_mul_1H11", {1, c.ar_heads, 1, 1}, SK_HOST, nullptr);
         L.qscale = walloc(m, c.ar_heads);
-        L.qkv_w = walloc(m, (int64_t)3 * kE * kE);
-        L.qkv_b = walloc(m, 3 * kE);     // key has no bias (app/transformer.py:61): stays zero
+        L.qkv_w = m->ar_qkv_w + (int64_t)i * 3 * kE * kE;
+        L.qkv_b = m->ar_qkv_b + (int64_t)i * 3 * kE;     // key has no bias (app/transformer.py:61): stays zero
         add_slot(m, p + ".attn.query.weight", {kE, kE}, SK_DIRECT, L.qkv_w);
         add_slot(m, p + ".attn.query.bias", {kE}, SK_DIRECT, L.qkv_b);
         add_slot(m, p + ".attn.key.weight", {kE, kE}, SK_DIRECT, L.qkv_w + (int64_t)kE * kE);
@@ -612,14 +618,26 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
     // K/V of the 181 history tokens, once per layer (raw prev tokens, not modulated: app/transformer.py:68-70)
     roctxRangePushA("artalk.ar.history_kv");
     if (p8) launch_pack_split(w.prev_in, reinterpret_cast<unsigned int*>(w.prev_in_p8), (long)B * kNTok * kE, false, s);   // one split for the 12 layers
-    for (int l = 0; l < c.ar_depth; ++l) {
-        const ARLayer& L = m->ar[l];
+    {
+        // all blocks in one launch: N = depth x (E keys + E values), column group l = block l's weight rows / cache columns
         GemmArgs g;
         g.A = p8 ? w.prev_in_p8 : w.prev_in; g.a_packed = p8;
-        g.lda = kE; g.W = L.qkv_w + (long)kE * kE; g.ldw = kE; g.bias = L.qkv_b + kE;
-        g.C = w.cache + l * cache_l + kE; g.ldc = 3 * kE; g.cmap = rowmap(kNTok, 2 * kNTok, 0);
-        g.M = B * kNTok; g.N = 2 * kE; g.K = kE;
-        gemm(m, g, s);
+        g.lda = kE; g.W = m->ar_qkv_w + (long)kE * kE; g.ldw = kE; g.bias = m->ar_qkv_b + kE;
+        g.C = w.cache + kE; g.ldc = 3 * kE; g.cmap = rowmap(kNTok, 2 * kNTok, 0);
+        g.M = B * kNTok; g.N = c.ar_depth * 2 * kE; g.K = kE;
+        g.ngrp = 2 * kE; g.grpW = (long)3 * kE * kE; g.grpB = 3 * kE; g.grpC = cache_l;
+        g.Wp = packed_of(m, g.W);
+        if (p8 && m->hist_kv_batched && gemm_p8_eligible(g)) {
+            gemm(m, g, s);
+        } else {
+            for (int l = 0; l < c.ar_depth; ++l) {          // exact-f32 mode / small batches: one launch per block
+                const ARLayer& L = m->ar[l];
+                GemmArgs q = g;
+                q.Wp = nullptr; q.ngrp = 0; q.grpW = q.grpB = q.grpC = 0;
+                q.W = L.qkv_w + (long)kE * kE; q.bias = L.qkv_b + kE; q.C = w.cache + l * cache_l + kE; q.N = 2 * kE;
+                gemm(m, q, s);
+            }
+        }
     }
     roctxRangePop();
     launch_ar_begin(w.style_cond, m->lvl_pos, w.x, w.fhat, B, s);
@@ -904,6 +922,7 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
     artalk_model* m = new artalk_model();
     m->cfg = c; m->device = device_id;
     if (const char* e = getenv("ARTALK_SM_SPLIT768")) m->sm_split_768 = atoi(e);
+    if (const char* e = getenv("ARTALK_HIST_KV_BATCHED")) m->hist_kv_batched = atoi(e);
     // conv stack geometry: T_l valid frames; row stride S_l per chunk with S_l = 2*S_{l+1} so that one GEMM covers all chunks
     int T = kSamplesPerChunk;
     for (int i = 0; i < c.w2v_n_conv; ++i) { T = (T - c.w2v_conv_kernel[i]) / c.w2v_conv_stride[i] + 1; m->conv_T[i] = T; }

@@ -705,6 +705,9 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
         tm = first_m + (in_g - tn * gsz);
     }
     const int m0 = tm * BM, n0 = tn * BN;
+    // column group of this tile (kernels.h): global column indices stay, the operand / result bases move
+    const int grp = g.ngrp ? n0 / g.ngrp : 0;
+    const long wgrp_off = grp ? (long)grp * (g.grpW - (long)g.ngrp * g.ldw) : 0;
 
     const int nk_all = g.K / BK;   // split-K (small grids): this workgroup owns K tiles [kt0, kt0 + nk)
     const int kt0 = (int)((long)nk_all * blockIdx.y / g.splitk);
@@ -719,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
         const int gn = min(n0 + ra, g.N - 1);
         const int sw = (pchunk ^ ((ra >> 1) & 7)) << 4;
         src[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda + (long)kt0 * BK) * 4 + sw;
-        src[4 + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw + (long)kt0 * BK) * 4 + sw;
+        src[4 + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw + (long)kt0 * BK + wgrp_off) * 4 + sw;
     }
     auto issue_piece = [&](int q, int kt, int buf) {
         unsigned char* dst = smem_p8 + buf * STAGE_BYTES + (q < 4 ? 0 : BM * 128) + (wave * 4 + (q & 3)) * 1024;
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
     kstep(kt, kt & 1, std::false_type{});
     if constexpr (ABL == 6) { if (tid == 0) stamps[2] = wall_clock64(); }
 
-    const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+    const EpiCtx epi = make_epi(g, g.bias ? g.bias + (long)grp * (g.grpB - g.ngrp) : nullptr, g.C + (long)grp * (g.grpC - g.ngrp), g.R);
     float* __restrict__ P = g.splitk > 1 ? g.partial + (long)blockIdx.y * g.M * g.N : nullptr;
     auto epi_tile = [&](auto i_tag, auto j_tag) {
         constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value;
@@ -871,12 +874,15 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
                 w_off[kb][lo] = lds0 + BM * 128 + wrow * 128 + ((c ^ wkey) << 4);
             }
     }
-    const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+    EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
     const bool can_defer = epi.vec && !g.R && !g.gate && nk >= 4;
+    float* const C0 = g.C;
+    const float* const bias0 = g.bias;
 
     f32x16 acc[2][2], keep[2][2];
     bool pending = false;
     int pm0 = 0, pn0 = 0;
+    float* pC = g.C;                 // result base of the kept (deferred) tile: its column group may differ from the current tile's
     const unsigned char* src[NDMA];
     f16x8 bh[2][2], bl[2][2], ah[2], al[2];
 
@@ -935,10 +941,10 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
         substep(kt_issue, buf, sb, issue_tag, I1{}, I1{});
         if (dq >= 0) {
             const int row0 = pm0 + wm * 64 + r, col0 = pn0 + wn * 64;
-            if (dq == 0) epilogue_tile32_store(g, epi.C, row0, col0, h, keep[0][0]);
-            else if (dq == 1) epilogue_tile32_store(g, epi.C, row0, col0 + 32, h, keep[0][1]);
-            else if (dq == 2) epilogue_tile32_store(g, epi.C, row0 + 32, col0, h, keep[1][0]);
-            else epilogue_tile32_store(g, epi.C, row0 + 32, col0 + 32, h, keep[1][1]);
+            if (dq == 0) epilogue_tile32_store(g, pC, row0, col0, h, keep[0][0]);
+            else if (dq == 1) epilogue_tile32_store(g, pC, row0, col0 + 32, h, keep[0][1]);
+            else if (dq == 2) epilogue_tile32_store(g, pC, row0 + 32, col0, h, keep[1][0]);
+            else epilogue_tile32_store(g, pC, row0 + 32, col0 + 32, h, keep[1][1]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -955,6 +961,8 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
         n0 = tn * BN;
     };
     auto set_src = [&](int m0, int n0) {
+        const int grp = g.ngrp ? n0 / g.ngrp : 0;          // column group (kernels.h): global column indices stay, the bases move
+        const long wgrp_off = grp ? (long)grp * (g.grpW - (long)g.ngrp * g.ldw) : 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ra = wave * 32 + q * 8 + prow;
@@ -962,7 +970,14 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
             const int gn = min(n0 + ra, g.N - 1);
             const int sw = (pchunk ^ ((ra >> 1) & 7)) << 4;
             src[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda) * 4 + sw;
-            src[4 + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw) * 4 + sw;
+            src[4 + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw + wgrp_off) * 4 + sw;
+        }
+    };
+    auto set_epi = [&](int n0) {     // result / bias bases of the tile whose accumulators are about to be finished
+        if (g.ngrp) {
+            const int grp = n0 / g.ngrp;
+            epi.C = C0 + (long)grp * (g.grpC - g.ngrp);
+            epi.bias = bias0 ? bias0 + (long)grp * (g.grpB - g.ngrp) : nullptr;
         }
     };
 
@@ -999,6 +1014,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
         ++gs;
         behind = 0;
         const bool full = m0 + BM <= g.M && n0 + BN <= g.N;
+        set_epi(n0);
         {   // (the launcher takes this kernel only when the 16-byte epilogue path applies: epi.vec)
             // results move to the kept registers (scaled, bias added); the accumulators are dead from here on
 #pragma unroll
@@ -1014,7 +1030,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
                         for (int e = 0; e < 4; ++e) keep[i][j][4 * q + e] = acc[i][j][4 * q + e] * kOutScale + b[e];
                 }
             if (can_defer && full) {
-                pending = true; pm0 = m0; pn0 = n0;
+                pending = true; pm0 = m0; pn0 = n0; pC = epi.C;
             } else {                 // edge tile, residual or gate: finish it now (bias is already in)
                 EpiCtx e2 = epi;
                 e2.bias = nullptr;
@@ -1032,10 +1048,10 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
     }
     if (pending) {
         const int row0 = pm0 + wm * 64 + r, col0 = pn0 + wn * 64;
-        epilogue_tile32_store(g, epi.C, row0, col0, h, keep[0][0]);
-        epilogue_tile32_store(g, epi.C, row0, col0 + 32, h, keep[0][1]);
-        epilogue_tile32_store(g, epi.C, row0 + 32, col0, h, keep[1][0]);
-        epilogue_tile32_store(g, epi.C, row0 + 32, col0 + 32, h, keep[1][1]);
+        epilogue_tile32_store(g, pC, row0, col0, h, keep[0][0]);
+        epilogue_tile32_store(g, pC, row0, col0 + 32, h, keep[0][1]);
+        epilogue_tile32_store(g, pC, row0 + 32, col0, h, keep[1][0]);
+        epilogue_tile32_store(g, pC, row0 + 32, col0 + 32, h, keep[1][1]);
     }
 }
 
@@ -1276,9 +1292,12 @@ void launch_gemm_p8(const GemmArgs& g, hipStream_t s) {
         case 9: hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, g); break;   // persistent, deferred epilogue
         case 19: hipLaunchKernelGGL((gemm_p8_2wg_kernel<7>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;   // ablation: no epilogue
         default:
-            if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wg_kernel<0, 1>), dim3(t128, g.splitk), dim3(256), 2 * 256 * 128, s, g);
-            else if (cfg == 8 && g.force_cfg < 0 && g.splitk == 1 && persist && epi_vec_host(g))     // production choice: persistent, deferred epilogue
-                hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, g);
+            if (cfg == 8 && g.force_cfg < 0 && g.splitk == 1 && persist && epi_vec_host(g) && (!g.graph_tag || t128 >= 1024)) {
+                // production choice: persistent, deferred epilogue (inside the captured AR/VAE body only for grids several rounds deep)
+                if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wgp_kernel<1>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, g);
+                else hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, g);
+            }
+            else if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wg_kernel<0, 1>), dim3(t128, g.splitk), dim3(256), 2 * 256 * 128, s, g);
             else hipLaunchKernelGGL((gemm_p8_2wg_kernel<0, 0>), dim3(t128, g.splitk), dim3(256), 2 * 256 * 128, s, g);
             break;
     }
@@ -1288,11 +1307,11 @@ void launch_gemm_p8(const GemmArgs& g, hipStream_t s) {
 // AdaLN table: 354 vs 329 and 330 vs 306 TF/s), loses on the encoder GEMMs (profiles/r01_gemm_f16s_bench.log).
 int gemm_p8_variant(const GemmArgs& g) {
     const long t256sq = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
-    return (t256sq >= 2560 && g.N % 256 == 0) ? 1 : 0;
+    return (t256sq >= 2560 && g.N % 256 == 0 && g.ngrp == 0) ? 1 : 0;      // column groups: the 128x128 kernels only
 }
 bool gemm_p8_eligible(const GemmArgs& g) {
     return g.Wp != nullptr && g.a_packed && g.amode == 0 && g.batch == 1 && g.splitk == 1 && g.K % 32 == 0 && (g.lda % 8) == 0 &&
-           (long)((g.M + 127) / 128) * ((g.N + 127) / 128) >= 384;
+           (long)((g.M + 127) / 128) * ((g.N + 127) / 128) >= 384 && (g.ngrp == 0 || (g.ngrp % 128 == 0 && g.N % g.ngrp == 0));
 }
 
 template <int BM, int BN, int WM, int WN>

@@ -45,6 +45,10 @@ struct GemmArgs {
     // split-K (small-M steps of the AR loop): grid.y = splitk workgroups share one output tile, each writes its raw partial
     // sums to partial[y][M][N]; launch_splitk_reduce adds them in a fixed order (deterministic) and applies the epilogue.
     int splitk = 1; float* partial = nullptr;
+    // column groups (the two 128x128 LDS-DMA kernels only): columns [j*ngrp, (j+1)*ngrp) are an independent linear layer j that
+    // shares A - weight rows at W + j*grpW, bias at bias + j*grpB, result columns at C + j*grpC (elements; ngrp % 128 == 0).
+    // One launch then computes the same input through many layers' weights (the history K/V of all 12 AR blocks).
+    int ngrp = 0; long grpW = 0, grpB = 0, grpC = 0;
     int force_cfg = -1;  // >= 0: tile configuration override (tuning/tests)
     int graph_tag = 0;   // 1 for launches inside the captured AR/VAE body (separate kernel symbol, same code)
 };
