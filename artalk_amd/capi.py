@@ -11,7 +11,7 @@ import os
 from .config import ARTalkConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libartalk_hip.so")
+LIB_PATH = os.environ.get("ARTALK_LIB") or os.path.join(_HERE, "libartalk_hip.so")     # ARTALK_LIB: A/B runs of two builds on one box
 
 OK, EINVAL, EKEY, EMISSING, EHIP, ESTATE, ECAPACITY, EBUSY = 0, -1, -2, -3, -4, -5, -6, -7
 DTYPE_F32, DTYPE_I64 = 0, 1
@@ -20,7 +20,7 @@ DTYPE_F32, DTYPE_I64 = 0, 1
 SYMBOLS = [
     "artalk_create", "artalk_destroy", "artalk_last_error", "artalk_set_tensor", "artalk_finalize_weights",
     "artalk_reserve", "artalk_workspace_bytes", "artalk_weight_bytes", "artalk_infer", "artalk_get_status", "artalk_poll_status", "artalk_style_encode", "artalk_stream_begin", "artalk_stream_chunk", "artalk_stream_end", "artalk_savgol", "artalk_flame_create", "artalk_flame_verts", "artalk_flame_destroy", "artalk_flame_last_error",
-    "artalk_set_profiling", "artalk_get_profile", "artalk_set_graphs", "artalk_set_overlap", "artalk_set_precision",
+    "artalk_set_profiling", "artalk_get_profile", "artalk_set_graphs", "artalk_set_overlap", "artalk_set_audit", "artalk_get_audit", "artalk_set_precision",
     "artalk_op_gemm", "artalk_op_gemm_ex", "artalk_op_gemm_f16s", "artalk_op_pack_split", "artalk_op_gemm_f16s_packed", "artalk_op_mfma_f32_peak", "artalk_op_layernorm", "artalk_op_attention", "artalk_op_w2v_front", "artalk_op_resample_mean", "artalk_op_pool_silu",
     "artalk_op_bsq_history",
 ]
@@ -128,6 +128,11 @@ def lib() -> C.CDLL:
     L.artalk_get_profile.restype = i32
     L.artalk_set_graphs.argtypes = [vp, i32]
     L.artalk_set_graphs.restype = i32
+    if hasattr(L, "artalk_set_audit"):      # (an older build loaded through ARTALK_LIB for an A/B run may lack it)
+        L.artalk_set_audit.argtypes = [vp, i32]
+        L.artalk_set_audit.restype = i32
+        L.artalk_get_audit.argtypes = [vp, C.c_char_p, i32, C.POINTER(C.c_float), i32]
+        L.artalk_get_audit.restype = i32
     L.artalk_set_overlap.argtypes = [vp, i32]
     L.artalk_set_overlap.restype = i32
     L.artalk_op_gemm.argtypes = [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]

@@ -78,6 +78,37 @@ __device__ __forceinline__ float area_pool(const float* f, int pn, int i, int c)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Headroom audit (artalk_set_audit): max |x| * 16 over a P8 buffer (the hi halves are f16(16 x)) or over an fp32 buffer that a
+// register-staged GEMM splits while staging; positive floats order like their bit patterns, so the maximum is an atomicMax.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ buf, int rows, int cols, long ld, int is_p8,
+                                                     unsigned int* __restrict__ slot, int junk_period, int junk_from) {
+    float m = 0.f;
+    const long groups = (long)rows * (cols / 8);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < groups; i += (long)gridDim.x * 256) {
+        const long r = i / (cols / 8), g8 = i - r * (cols / 8);
+        if (junk_period && r % junk_period >= junk_from) continue;      // layout padding rows (conv stack)
+        const float* p = buf + r * ld + g8 * 8;
+        if (is_p8) {
+            const _Float16* h = reinterpret_cast<const _Float16*>(p);      // [8 x hi][8 x lo]
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)h[e]));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(p[e]) * kActScale);
+        }
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+}
+void launch_absmax(const float* buf, int rows, int cols, long ld, int is_p8, unsigned int* slot, hipStream_t s, int junk_period, int junk_from) {
+    if (rows <= 0 || cols < 8) return;
+    const long groups = (long)rows * (cols / 8);
+    const long blocks = (groups + 255) / 256;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, buf, rows, cols, ld, is_p8, slot, junk_period,
+                       junk_from);
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ar_begin_kernel(const float* __restrict__ style_cond, const float* __restrict__ lvlpos,
                                                        float* __restrict__ x0, float* __restrict__ fhat, int E) {
     const int b = blockIdx.x;

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             const int d0 = NDT * (4 * g + reg);
             if constexpr (NDT == 4) {
                 const float o0 = ot[0][reg] * inv, o1 = ot[1][reg] * inv, o2 = ot[2][reg] * inv, o3 = ot[3][reg] * inv;
-                if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3);   // op is 32-byte aligned (HD % 8 == 0)
+                if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status);   // op is 32-byte aligned (HD % 8 == 0)
                 else { f32x4 o = {o0, o1, o2, o3}; *reinterpret_cast<f32x4*>(op + d0) = o; }
             } else {
                 *reinterpret_cast<float2*>(op + d0) = make_float2(ot[0][reg] * inv, ot[NDT - 1][reg] * inv);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const AttnArgs a) 
         if (q0 + q < a.Lq) {
             const float inv = 1.0f / L;
             float* op = a.O + (long)b * a.o_bstride + (long)(q0 + q) * a.ldo + h * HD;
-            if (a.out_p8) store_p8x4(op, 4 * dc, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+            if (a.out_p8) store_p8x4(op, 4 * dc, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv, a.status);
             else { const f32x4 v = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv}; *reinterpret_cast<f32x4*>(op + 4 * dc) = v; }
         }
     }
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
         for (int dt = 0; dt < 4; ++dt) {
             const int d0 = 16 * dt + 4 * g;
             const float o0 = ot[dt][0] * inv, o1 = ot[dt][1] * inv, o2 = ot[dt][2] * inv, o3 = ot[dt][3] * inv;
-            if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3);
+            if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status);
             else { const f32x4 o = {o0, o1, o2, o3}; *reinterpret_cast<f32x4*>(op + d0) = o; }
         }
     }

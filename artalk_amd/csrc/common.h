@@ -50,8 +50,32 @@ __device__ __forceinline__ void split_f16(float xs, _Float16& hi, _Float16& lo) 
     hi = (_Float16)xs;
     lo = (_Float16)(xs - (float)hi);
 }
+// Range guard of every P8 producer: an activation with |x| * kActScale beyond fp16's largest finite value (or a NaN) would become
+// inf in the hi half and poison every product it takes part in; the producer reports it in the model's status word (bit 3,
+// include/artalk_hip.h: artalk_get_status) at the place it happens instead of relying on the NaN reaching a bit decision.
+constexpr int kStatusP8Range = 8;
+// |x| * kActScale <= 65504 (fp16's largest finite value), as a bound on the bit pattern of |x|: finite positive floats order like
+// their bit patterns and NaN / inf patterns lie above every finite one, so ONE unsigned maximum + ONE compare covers range, inf
+// and NaN (an fmaxf chain would drop NaNs and need a compare per element).
+constexpr unsigned int kP8MaxBits = 0x457FE000u;      // bits of 4094.0f = 65504 / 16
+__device__ __forceinline__ unsigned int abs_bits(float x) { return __float_as_uint(x) & 0x7FFFFFFFu; }
+__device__ __forceinline__ void p8_guard(int* status, float a, float b, float c, float d) {
+    if (status) {
+        const unsigned int m = max(max(abs_bits(a), abs_bits(b)), max(abs_bits(c), abs_bits(d)));
+        if (m > kP8MaxBits) atomicOr(status, kStatusP8Range);
+    }
+}
+__device__ __forceinline__ void p8_guard16(int* status, const f32x16& v) {      // one compare for a whole 32x32 MFMA sub-tile
+    if (status) {
+        unsigned int m = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m = max(m, abs_bits(v[e]));
+        if (m > kP8MaxBits) atomicOr(status, kStatusP8Range);
+    }
+}
 // store_p8x4 writes activation elements c..c+3 (c % 4 == 0) of a row whose storage starts at `row`.
-__device__ __forceinline__ void store_p8x4(float* row, int c, float x0, float x1, float x2, float x3) {
+__device__ __forceinline__ void store_p8x4(float* row, int c, float x0, float x1, float x2, float x3, int* status = nullptr) {
+    p8_guard(status, x0, x1, x2, x3);
     const float x[4] = {x0, x1, x2, x3};
     f16x4_t h, l;
 #pragma unroll
@@ -63,7 +87,8 @@ __device__ __forceinline__ void store_p8x4(float* row, int c, float x0, float x1
 
 // The same for lanes that own ADJACENT runs of 4 columns (lane L: c, lane L+1: c+4 of one 8-group, L even; all 64 lanes active):
 // neighbours trade halves so that each issues ONE 16-byte store (even lane the hi chunk, odd lane the lo chunk) instead of two 8-byte ones.
-__device__ __forceinline__ void store_p8x4_pair(float* row, int c, float x0, float x1, float x2, float x3) {
+__device__ __forceinline__ void store_p8x4_pair(float* row, int c, float x0, float x1, float x2, float x3, int* status = nullptr) {
+    p8_guard(status, x0, x1, x2, x3);
     const float x[4] = {x0, x1, x2, x3};
     f16x4_t h, l;
 #pragma unroll
@@ -119,6 +144,11 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
             }
         }
         if (g.c_p8) {   // N % 8 == 0.  Pairs of 8-column groups (k, k+1): lanes h=0 end up with all of group k, lanes h=1 with group k+1
+            if (rok) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (col0 + 8 * q + 4 * h < g.N) p8_guard(g.status, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            }
 #pragma unroll
             for (int qp = 0; qp < 2; ++qp) {
                 unsigned int w[2][4];     // [group of the pair][hi.x, hi.y, lo.x, lo.y] of this lane's 4 columns
@@ -168,6 +198,7 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
             if (gp) t *= gp[col];
             if (rp) t += rp[col];
             if (g.c_p8) {
+                p8_guard(g.status, t, 0.f, 0.f, 0.f);
                 _Float16* o = reinterpret_cast<_Float16*>(x.C + crow * g.ldc + (col & ~7));
                 _Float16 hh, ll;
                 split_f16(t * kActScale, hh, ll);
@@ -188,6 +219,7 @@ __device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* 
         for (int e = 0; e < 16; ++e) v[e] = apply_act_rt(v[e], g.act);
     }
     if (g.c_p8) {
+        p8_guard16(g.status, v);
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
             unsigned int w[2][4];
@@ -238,6 +270,7 @@ __device__ __forceinline__ void epilogue_row4(const GemmArgs& g, const EpiCtx& x
         v[e] = t + rv[e];
     }
     if (g.c_p8) {
+        if (ok) p8_guard(g.status, v[0], v[1], v[2], v[3]);
         f16x4_t hh, ll;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { _Float16 a, c; split_f16(v[e] * kActScale, a, c); hh[e] = a; ll[e] = c; }

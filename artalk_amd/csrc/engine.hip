@@ -105,6 +105,11 @@ struct artalk_model {
     std::vector<PackRange> wranges;   // every weight allocation and its packed f16x3 copy (built at finalize)
     int precision = 0;                // 0: fp32 MFMA everywhere, 1: f16x3 split GEMMs (heads stay fp32)
     int splitk_tiles = 192, splitk_target = 384;   // split-K when the grid has fewer tiles than splitk_tiles; aim at splitk_target workgroups
+    // headroom audit (artalk_set_audit): max |x| * 16 at every producer of a P8 operand, by site name
+    bool audit = false;
+    unsigned int* audit_vals = nullptr;            // device, kAuditSlots floats (as bits)
+    std::vector<std::string> audit_names;
+    std::map<std::string, int> audit_index;
     int hist_kv_batched = 1;          // tuning (ARTALK_HIST_KV_BATCHED): history K/V of all blocks as one GEMM over column groups
     int sm_split_768 = 1;             // tuning (ARTALK_SM_SPLIT768): split K = 768 GEMMs of the smallest scale steps too (deep-ring kernels)
     int stream_B = 0;                 // streams opened by artalk_stream_begin (history lives in the workspace)
@@ -385,9 +390,26 @@ void stage_mark(artalk_model* m, hipStream_t s, int bucket) {
 // fuse_ln: the AdaLN-modulated LayerNorm that consumes this GEMM's (768-wide, residual-stream) result.  If the GEMM is split
 // over K, its reduce pass also writes that LayerNorm's output (one launch instead of two) and gemm() returns true; otherwise
 // the caller launches the LayerNorm itself.
+constexpr int kAuditSlots = 1024;
+// audit hook: records max |x| * 16 of a just-produced P8 buffer (or of an fp32 buffer a register-staged GEMM will split)
+void audit(artalk_model* m, const std::string& site, const float* buf, int rows, int cols, long ld, bool is_p8, hipStream_t s,
+           int junk_period = 0, int junk_from = 0) {
+    if (!m->audit || !m->audit_vals || m->precision != 1) return;
+    auto it = m->audit_index.find(site);
+    int idx;
+    if (it == m->audit_index.end()) {
+        if ((int)m->audit_names.size() >= kAuditSlots) return;
+        idx = (int)m->audit_names.size();
+        m->audit_names.push_back(site);
+        m->audit_index.emplace(site, idx);
+    } else idx = it->second;
+    launch_absmax(buf, rows, cols & ~7, ld, is_p8 ? 1 : 0, m->audit_vals + idx, s, junk_period, junk_from);
+}
+
 bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse_ln = nullptr) {
     GemmArgs g = g0;
     g.graph_tag = m->in_body ? 1 : 0;
+    g.status = m->precision == 1 ? (m->view ? m->view->status : m->ws.status) : nullptr;     // P8 range guard at the producers
     bool split = false;
     if (m->precision == 1 && !g.exact) {
         g.Wp = packed_of(m, g.W);
@@ -457,9 +479,10 @@ void linear(artalk_model* m, const float* A, long lda, const float* W, const flo
     gemm(m, g, s);
 }
 
-void layernorm(const float* X, float* Y, const float* w, const float* b, int M, int D, float eps, int act, hipStream_t s, int out_p8 = 0) {
+void layernorm(const float* X, float* Y, const float* w, const float* b, int M, int D, float eps, int act, hipStream_t s, int out_p8 = 0,
+               int* status = nullptr, int junk_period = 0, int junk_from = 0) {
     LnArgs a;
-    a.out_p8 = out_p8;
+    a.out_p8 = out_p8; a.status = out_p8 ? status : nullptr; a.junk_period = junk_period; a.junk_from = junk_from;
     a.X = X; a.ldx = D; a.Y = Y; a.ldy = D; a.w = w; a.b = b; a.M = M; a.D = D; a.eps = eps; a.act = act;
     launch_layernorm(a, s);
 }
@@ -478,7 +501,8 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     roctxRangePushA("artalk.wav2vec2.conv_stack");      // K1-K3: normalise, conv0+LN+GELU, conv1-6 as GEMMs + LN + GELU
     launch_audio_normalize(audio, w.src_off + c0, w.xnorm, n, kSamplesPerChunk, s);
     launch_conv0(w.xnorm, kSamplesPerChunk, m->conv0_w, m->conv_b[0], m->conv_lnw[0], m->conv_lnb[0], w.convA, n, m->conv_T[0],
-                 m->conv_S[0], s, p8);
+                 m->conv_S[0], s, p8, w.status);
+    audit(m, "w2v.conv0.ln_gelu", w.convA, n * m->conv_S[0], CD, CD, p8, s, m->conv_S[0], m->conv_T[0]);
     float* src = w.convA; float* dst = w.convB;
     for (int i = 1; i < c.w2v_n_conv; ++i) {
         // stride-2 conv as a GEMM: output row r reads input rows 2r..2r+k-1 (contiguous K = k*512 floats)
@@ -486,15 +510,23 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
         linear(m, src, (long)c.w2v_conv_stride[i] * CD, m->conv_w[i], m->conv_b[i], dst, CD, M, CD, c.w2v_conv_kernel[i] * CD,
                ACT_NONE, nullptr, s, AP);
         // the last conv output feeds a LayerNorm (feature projection), not a GEMM: it stays fp32
-        layernorm(dst, dst, m->conv_lnw[i], m->conv_lnb[i], M, CD, 1e-5f, ACT_GELU_ERF, s, (p8 && i + 1 < c.w2v_n_conv) ? 1 : 0);
+        // rows t >= conv_T[i] of every chunk are layout padding (computed from the padding rows below them): no range guard there
+        layernorm(dst, dst, m->conv_lnw[i], m->conv_lnb[i], M, CD, 1e-5f, ACT_GELU_ERF, s, (p8 && i + 1 < c.w2v_n_conv) ? 1 : 0, w.status,
+                  m->conv_S[i], m->conv_T[i]);
+        if (i + 1 < c.w2v_n_conv) audit(m, "w2v.conv" + std::to_string(i) + ".ln_gelu", dst, M, CD, CD, p8, s, m->conv_S[i], m->conv_T[i]);
         std::swap(src, dst);
     }
     stage_mark(m, s, PB_CONV);
     roctxRangePop();
     Range r_enc("artalk.wav2vec2.encoder");             // K4-K7: projection, pos-conv, 24 layers, final LN, pooling + SiLU
     const int M = n * m->Ts;
+    // hidden states use a 200-row stride per chunk, 199 valid.  The padding row is never read by a valid row; the LayerNorms store
+    // it as zeros (LnArgs::junk_period), and the attention output's padding row is never written (zero since allocation), so
+    // everything computed in it stays finite and inside the P8 range without the GEMM epilogues having to know about it.
+    const int JP = m->Ts, JF = m->Tw;
     // feature projection (hf:429-434)
-    layernorm(src, dst, m->fp_lnw, m->fp_lnb, M, CD, c.w2v_ln_eps, ACT_NONE, s, p8);
+    layernorm(src, dst, m->fp_lnw, m->fp_lnb, M, CD, c.w2v_ln_eps, ACT_NONE, s, p8, w.status, JP, JF);
+    audit(m, "w2v.feature_projection.ln", dst, M, CD, CD, p8, s, JP, JF);
     linear(m, dst, CD, m->fp_w, m->fp_b, w.h0, Hs, M, Hs, CD, ACT_NONE, nullptr, s, AP);
     // positional conv embedding (hf:360-368): h1 = h0 + gelu(groupconv(h0) + b)   (fp32 kernel: gathers the padded window)
     {
@@ -510,7 +542,9 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     const int nh = c.w2v_heads, hd = Hs / nh;
     for (int i = 0; i < c.w2v_layers; ++i) {
         const W2VLayer& L = m->w2v[i];
-        layernorm(h, w.xln, L.ln1w, L.ln1b, M, Hs, c.w2v_ln_eps, ACT_NONE, s, p8);
+        const std::string an = "w2v.layer" + std::to_string(i);
+        layernorm(h, w.xln, L.ln1w, L.ln1b, M, Hs, c.w2v_ln_eps, ACT_NONE, s, p8, w.status, JP, JF);
+        audit(m, an + ".ln1", w.xln, M, Hs, Hs, p8, s, JP, JF);
         linear(m, w.xln, Hs, L.qkv_w, L.qkv_b, w.qkv, 3 * Hs, M, 3 * Hs, Hs, ACT_NONE, nullptr, s, AP | (p8 ? LF_C_P8 : 0));   // q, k, v leave in P8
         AttnArgs a;
         a.qkv_p8 = p8;
@@ -518,18 +552,23 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
         a.ldq = a.ldk = a.ldv = 3 * Hs; a.q_bstride = a.k_bstride = a.v_bstride = (long)m->Ts * 3 * Hs;
         a.O = w.att; a.ldo = Hs; a.o_bstride = (long)m->Ts * Hs;
         a.B = n; a.H = nh; a.HD = hd; a.Lq = m->Tw; a.Lk = m->Tw; a.scale = 1.0f / std::sqrt((float)hd);
-        a.out_p8 = p8; a.split16 = p8;
+        audit(m, an + ".qkv", w.qkv, M, 3 * Hs, 3 * Hs, p8, s, JP, JF);
+        a.out_p8 = p8; a.split16 = p8; a.status = p8 ? w.status : nullptr;
         launch_attention(a, s);
+        audit(m, an + ".attn_out", w.att, M, Hs, Hs, p8, s, JP, JF);
         linear(m, w.att, Hs, L.out_w, L.out_b, h, Hs, M, Hs, Hs, ACT_NONE, h, s, AP);
-        layernorm(h, w.xln, L.ln2w, L.ln2b, M, Hs, c.w2v_ln_eps, ACT_NONE, s, p8);
+        layernorm(h, w.xln, L.ln2w, L.ln2b, M, Hs, c.w2v_ln_eps, ACT_NONE, s, p8, w.status, JP, JF);
+        audit(m, an + ".ln2", w.xln, M, Hs, Hs, p8, s, JP, JF);
         linear(m, w.xln, Hs, L.ff1_w, L.ff1_b, w.ffn, c.w2v_ffn, M, c.w2v_ffn, Hs, ACT_GELU_ERF, nullptr, s, AP | (p8 ? LF_C_P8 : 0));
+        audit(m, an + ".ffn_hidden", w.ffn, M, c.w2v_ffn, c.w2v_ffn, p8, s, JP, JF);
         linear(m, w.ffn, c.w2v_ffn, L.ff2_w, L.ff2_b, h, Hs, M, Hs, c.w2v_ffn, ACT_NONE, h, s, AP);
     }
     layernorm(h, w.xln, m->enc_lnw, m->enc_lnb, M, Hs, c.w2v_ln_eps, ACT_NONE, s);
     if (out_w2v)
         (void)hipMemcpy2DAsync(out_w2v + (long)c0 * m->Tw * Hs, (size_t)m->Tw * Hs * 4, w.xln, (size_t)m->Ts * Hs * 4,
                                (size_t)m->Tw * Hs * 4, n, hipMemcpyDeviceToDevice, s);
-    launch_pool_silu(w.xln, m->Ts, m->Tw, w.silu_cond + (long)c0 * kNTok * kCond, n, m->pn, c.n_levels, kCond, s, p8);
+    launch_pool_silu(w.xln, m->Ts, m->Tw, w.silu_cond + (long)c0 * kNTok * kCond, n, m->pn, c.n_levels, kCond, s, p8, w.status);
+    audit(m, "ar.silu_cond", w.silu_cond + (long)c0 * kNTok * kCond, n * kNTok, kCond, kCond, p8, s);
     stage_mark(m, s, PB_ENC);
 }
 
@@ -574,7 +613,9 @@ void run_vae_stack(artalk_model* m, const VAESide& S, int B, int T, int split, h
     const int AP = p8 ? LF_A_P8 : 0;
     for (int i = 0; i < c.vae_depth; ++i) {
         const VAELayer& L = S.layers[i];
-        layernorm(w.vh, w.vln, L.lnw, L.lnb, M, H, 1e-5f, ACT_NONE, s, p8);
+        const std::string an = std::string(&S == &m->enc ? "vae.encoder.layer" : "vae.decoder.layer") + std::to_string(i);
+        layernorm(w.vh, w.vln, L.lnw, L.lnb, M, H, 1e-5f, ACT_NONE, s, p8, w.status);
+        audit(m, an + ".ln", w.vln, M, H, H, p8, s);
         linear(m, w.vln, H, L.qkv_w, nullptr, w.vqkv, 3 * H, M, 3 * H, H, ACT_NONE, nullptr, s, AP | (p8 ? LF_C_P8 : 0));   // q, k, v leave in P8
         AttnArgs a;
         a.qkv_p8 = p8;
@@ -583,10 +624,14 @@ void run_vae_stack(artalk_model* m, const VAESide& S, int B, int T, int split, h
         a.O = w.vatt; a.ldo = H; a.o_bstride = (long)T * H;
         a.B = B; a.H = c.vae_heads; a.HD = H / c.vae_heads; a.Lq = T; a.Lk = T;
         a.scale = 1.0f / std::sqrt((float)H);      // hidden_dim**-0.5, NOT head_dim (bitwise_vae.py:198)
-        a.split_q = split; a.split_k = split; a.out_p8 = p8; a.split16 = p8;
+        audit(m, an + ".qkv", w.vqkv, M, 3 * H, 3 * H, p8, s);
+        a.split_q = split; a.split_k = split; a.out_p8 = p8; a.split16 = p8; a.status = p8 ? w.status : nullptr;
         launch_attention(a, s);
+        audit(m, an + ".attn_out", w.vatt, M, H, H, p8, s);
         linear(m, w.vatt, H, L.out_w, L.out_b, w.vh, H, M, H, H, ACT_NONE, w.vh, s, AP);
+        audit(m, an + ".residual(fp32 A of mlp.0)", w.vh, M, H, H, false, s);
         linear(m, w.vh, H, L.m1_w, L.m1_b, w.vmlp, F, M, F, H, ACT_GELU_TANH, nullptr, s, p8 ? LF_C_P8 : 0);   // A = residual stream (fp32)
+        audit(m, an + ".mlp_hidden", w.vmlp, M, F, F, p8, s);
         linear(m, w.vmlp, F, L.m2_w, L.m2_b, w.vh, H, M, H, F, ACT_NONE, w.vh, s, AP);
     }
 }
@@ -597,6 +642,7 @@ void run_reencode(artalk_model* m, int B, hipStream_t s) {
     Workspace& w = m->view ? *m->view : m->ws;
     const int H = c.vae_hidden, T = 100;
     Range r_re("artalk.vae.reencode_bsq");              // K16-K17: encoder, multi-scale BSQ, history features
+    audit(m, "vae.encoder.input(fp32 A)", w.enc_in, B * T, 128, 128, false, s);
     linear(m, w.enc_in, 128, m->enc.in_w, m->enc.in_b, w.vh, H, B * T, H, 128, ACT_LEAKY02, nullptr, s);
     run_vae_stack(m, m->enc, B, T, 0, s);
     linear(m, w.vh, H, m->enc.out_w, m->enc.out_b, w.enc_out, c.code_dim, B * T, c.code_dim, H, ACT_NONE, nullptr, s, LF_EXACT);
@@ -617,7 +663,8 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
     const int p8 = m->precision == 1 ? 1 : 0;
     // K/V of the 181 history tokens, once per layer (raw prev tokens, not modulated: app/transformer.py:68-70)
     roctxRangePushA("artalk.ar.history_kv");
-    if (p8) launch_pack_split(w.prev_in, reinterpret_cast<unsigned int*>(w.prev_in_p8), (long)B * kNTok * kE, false, s);   // one split for the 12 layers
+    if (p8) launch_pack_split(w.prev_in, reinterpret_cast<unsigned int*>(w.prev_in_p8), (long)B * kNTok * kE, false, s, w.status);   // one split for the 12 layers
+    audit(m, "ar.history_tokens", p8 ? w.prev_in_p8 : w.prev_in, B * kNTok, kE, kE, p8, s);
     {
         // all blocks in one launch: N = depth x (E keys + E values), column group l = block l's weight rows / cache columns
         GemmArgs g;
@@ -652,6 +699,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
         auto ln_args = [&](int l, int which) {
             LnArgs n;
             n.X = w.x; n.ldx = kE; n.Y = w.xmod; n.ldy = kE; n.ldm = ldada; n.mmap = amap; n.M = M; n.D = kE; n.eps = 1e-6f;
+            n.status = p8 ? w.status : nullptr;
             if (l < c.ar_depth) {
                 const float* ada = w.ada + (long)l * 6 * kE;   // gamma1,gamma2,scale1,scale2,shift1,shift2 (app/transformer.py:32)
                 n.scale = ada + (2 + which) * kE; n.shift = ada + (4 + which) * kE; n.out_p8 = p8;
@@ -666,7 +714,9 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
             const ARLayer& L = m->ar[l];
             const float* ada = w.ada + (long)l * 6 * kE;
             float* cache = w.cache + l * cache_l;
+            const std::string an = "ar.block" + std::to_string(l);
             if (!have_ln) launch_layernorm(ln_args(l, 0), s);
+            audit(m, an + ".ln1_mod", w.xmod, M, kE, kE, p8, s);
             GemmArgs q;
             q.A = w.xmod; q.lda = kE; q.W = L.qkv_w; q.ldw = kE; q.bias = L.qkv_b; q.C = cache; q.ldc = 3 * kE;
             q.cmap = rowmap(pn, 2 * kNTok, kNTok + off); q.M = M; q.N = 3 * kE; q.K = kE; q.a_packed = p8;
@@ -676,14 +726,17 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
             a.ldq = a.ldk = a.ldv = 3 * kE; a.q_bstride = a.k_bstride = a.v_bstride = (long)2 * kNTok * 3 * kE;
             a.O = w.attn_out; a.ldo = kE; a.o_bstride = (long)pn * kE;
             a.B = B; a.H = c.ar_heads; a.HD = kE / c.ar_heads; a.Lq = pn; a.Lk = kNTok + off + pn; a.scale = 1.0f;
-            a.l2norm = 1; a.qscale = L.qscale; a.out_p8 = p8; a.split16 = p8;
+            a.l2norm = 1; a.qscale = L.qscale; a.out_p8 = p8; a.split16 = p8; a.status = p8 ? w.status : nullptr;
             launch_attention(a, s);
+            audit(m, an + ".attn_out", w.attn_out, M, kE, kE, p8, s);
             GemmArgs pj;
             pj.A = w.attn_out; pj.lda = kE; pj.W = L.proj_w; pj.ldw = kE; pj.bias = L.proj_b; pj.C = w.x; pj.ldc = kE;
             pj.gate = ada; pj.ldg = ldada; pj.gmap = amap; pj.R = w.x; pj.ldr = kE; pj.M = M; pj.N = kE; pj.K = kE; pj.a_packed = p8;
             const LnArgs n2 = ln_args(l, 1);
             if (!gemm(m, pj, s, &n2)) launch_layernorm(n2, s);
+            audit(m, an + ".ln2_mod", w.xmod, M, kE, kE, p8, s);
             linear(m, w.xmod, kE, L.ffn1_w, L.ffn1_b, w.ffn_h, 4 * kE, M, 4 * kE, kE, ACT_GELU_TANH, nullptr, s, p8 ? (LF_A_P8 | LF_C_P8) : 0);
+            audit(m, an + ".ffn_hidden", w.ffn_h, M, 4 * kE, 4 * kE, p8, s);
             GemmArgs f2;
             f2.A = w.ffn_h; f2.lda = 4 * kE; f2.W = L.ffn2_w; f2.ldw = 4 * kE; f2.bias = L.ffn2_b; f2.C = w.x; f2.ldc = kE;
             f2.gate = ada + kE; f2.ldg = ldada; f2.gmap = amap; f2.R = w.x; f2.ldr = kE; f2.M = M; f2.N = kE; f2.K = 4 * kE; f2.a_packed = p8;
@@ -702,8 +755,10 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
     const int H = c.vae_hidden;
     roctxRangePushA("artalk.vae.decode");               // K15
     launch_dec_input(w.prev_fdec, w.fhat, w.bits, m->dec_pos, w.dec_x, B, s);
+    audit(m, "vae.decoder.input(fp32 A)", w.dec_x, B * 200, c.code_dim, c.code_dim, false, s);
     linear(m, w.dec_x, c.code_dim, m->dec.in_w, m->dec.in_b, w.vh, H, B * 200, H, c.code_dim, ACT_LEAKY02, nullptr, s);
     run_vae_stack(m, m->dec, B, 200, 100, s);
+    audit(m, "vae.decoder.output_head(fp32 A)", w.vh, B * 200, H, H, false, s);
     linear(m, w.vh, H, m->dec.out_w, m->dec.out_b, w.dec_out, c.motion_dim, B * 200, c.motion_dim, H, ACT_NONE, nullptr, s);
     launch_dec_finish(w.dec_out, m->vae_mean, m->vae_std, m->enc_pos, w.motion_chunk, 100L * c.motion_dim, 0, w.enc_in, B, s, w.status);
     roctxRangePop();
@@ -737,7 +792,7 @@ Workspace clip_view(const artalk_model* m, int b0, int branch) {
 // becomes a fork/join in the hipGraph): one half's GPU-filling step overlaps the other half's latency-bound ones.
 int ensure_side_streams(artalk_model* m, int n);
 int run_chunk_body_split(artalk_model* m, int B, hipStream_t s) {
-    if (B < 8 || m->profiling == 2 || m->branches == 1) { run_chunk_body(m, B, s); return ARTALK_OK; }
+    if (B < 8 || m->profiling == 2 || m->branches == 1 || m->audit) { run_chunk_body(m, B, s); return ARTALK_OK; }
     if (int rc = ensure_side_streams(m, 1)) return rc;
     const int B0 = (B + 1) / 2, B1 = B - B0;
     Workspace v0 = clip_view(m, 0, 0), v1 = clip_view(m, B0, 1);
@@ -1122,6 +1177,44 @@ int artalk_set_graphs(artalk_model* m, int enable) {
     return ARTALK_OK;
 }
 
+// Headroom audit of the f16x3 operand format (tools/p8_headroom.py): while enabled, every artalk_infer runs without graphs and
+// records, per producer site of a P8 operand, max |x| * 16 (the value that must stay below fp16's 65504).  artalk_get_audit
+// synchronises the device and returns the number of sites; names are written NUL-separated into names_buf.
+int artalk_set_audit(artalk_model* m, int enable) {
+    if (!m) return ARTALK_EINVAL;
+    (void)hipSetDevice(m->device);
+    if (enable && !m->audit_vals) {
+        HIPCHK(m, hipMalloc(reinterpret_cast<void**>(&m->audit_vals), kAuditSlots * sizeof(unsigned int)));
+        m->allocs.push_back(m->audit_vals);
+    }
+    if (enable) {
+        HIPCHK(m, hipDeviceSynchronize());
+        HIPCHK(m, hipMemset(m->audit_vals, 0, kAuditSlots * sizeof(unsigned int)));
+        m->audit_names.clear(); m->audit_index.clear();
+    }
+    m->audit = enable != 0;
+    return ARTALK_OK;
+}
+int artalk_get_audit(artalk_model* m, char* names_buf, int buf_len, float* values, int max_n) {
+    if (!m || !names_buf || !values || buf_len <= 0 || max_n <= 0) return ARTALK_EINVAL;
+    if (!m->audit_vals) return 0;
+    (void)hipSetDevice(m->device);
+    if (hipDeviceSynchronize() != hipSuccess) return ARTALK_EHIP;
+    const int n = std::min<int>((int)m->audit_names.size(), max_n);
+    std::vector<unsigned int> bits((size_t)std::max(n, 1));
+    if (n && hipMemcpy(bits.data(), m->audit_vals, n * sizeof(unsigned int), hipMemcpyDeviceToHost) != hipSuccess) return ARTALK_EHIP;
+    int pos = 0, written = 0;
+    for (int i = 0; i < n; ++i) {
+        const std::string& nm = m->audit_names[i];
+        if (pos + (int)nm.size() + 1 > buf_len) break;
+        std::memcpy(names_buf + pos, nm.c_str(), nm.size() + 1);
+        pos += (int)nm.size() + 1;
+        std::memcpy(&values[i], &bits[i], sizeof(float));
+        ++written;
+    }
+    return written;
+}
+
 int artalk_set_overlap(artalk_model* m, int enable) {
     if (!m) return ARTALK_EINVAL;
     m->overlap = enable ? 1 : 0;
@@ -1220,7 +1313,7 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
         HIPCHK(m, hipMemcpy2DAsync(out_hist_bits_dev, (size_t)(maxch + 1) * bits_row, w.hist_bits, bits_row, bits_row, B,
                                    hipMemcpyDeviceToDevice, s));
     stage_mark(m, s, PB_VAE);
-    const bool graphs = m->use_graphs && m->profiling != 2;
+    const bool graphs = m->use_graphs && m->profiling != 2 && !m->audit;
     for (int64_t j = 0; j < maxch; ++j) {
         const int Bn = Bj[j];
         if (overlap) HIPCHK(m, hipStreamWaitEvent(s, m->w2v_done[j], 0));

@@ -43,9 +43,14 @@ __device__ __forceinline__ int p8_lds_offset(int c) { return (c & 1) * 64 + (c >
 // fp32 -> "P8" split format, 8 elements per thread: each group of 8 consecutive elements becomes 32 bytes
 // [8 x f16 hi][8 x f16 lo] (same size as the 8 floats it replaces, so a P8 matrix keeps the fp32 matrix's pitch and
 // indexing).  A 16-byte chunk of a P8 row is therefore directly an MFMA operand fragment (k = 8h .. 8h+7).
-__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, unsigned int* __restrict__ out, long n, float scale) {
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, unsigned int* __restrict__ out, long n, float scale,
+                                                         int* __restrict__ status) {
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long)gridDim.x * 2048) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(w + i), b = *reinterpret_cast<const f32x4*>(w + i + 4);
+        if (status) {      // activations only (scale = kActScale): range guard of the P8 format
+            p8_guard(status, a[0], a[1], a[2], a[3]);
+            p8_guard(status, b[0], b[1], b[2], b[3]);
+        }
         u32x2 h0, l0, h1, l1;
         split_f32x4(a, scale, h0, l0);
         split_f32x4(b, scale, h1, l1);
@@ -54,10 +59,11 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
         *reinterpret_cast<u32x4*>(out + i + 4) = lo;
     }
 }
-void launch_pack_split(const float* w, unsigned int* out, long n, bool is_weight, hipStream_t s) {
+void launch_pack_split(const float* w, unsigned int* out, long n, bool is_weight, hipStream_t s, int* status) {
     if (n <= 0) return;
+    if (is_weight) status = nullptr;
     const long blocks = (n / 8 + 255) / 256;   // n % 8 == 0 (every packed tensor has an inner dimension that is a multiple of 32)
-    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, w, out, n, is_weight ? kWScale : kActScale);
+    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, w, out, n, is_weight ? kWScale : kActScale, status);
 }
 
 // AMODE 1: grouped positional-conv window gather (see gemm_f32.hip), grid.z = group, fp32 A only.
@@ -129,6 +135,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
                 *reinterpret_cast<u32x4*>(p + p8_lds_offset(tid & 7)) = ra[i];
             } else {
                 u32x2 hi, lo;
+                {
+                    const f32x4 av = __builtin_bit_cast(f32x4, ra[i]);
+                    p8_guard(g.status, av[0], av[1], av[2], av[3]);
+                }
                 split_f32x4(__builtin_bit_cast(f32x4, ra[i]), kActScale, hi, lo);
                 *reinterpret_cast<u32x2*>(p + lc4 * 2) = hi;
                 *reinterpret_cast<u32x2*>(p + lc4 * 2 + 64) = lo;
@@ -672,6 +682,22 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
 // them), in its prologue, at its barrier or waiting for a DMA stage, the other one owns the matrix cores.  Same two-stage
 // K-step structure as the 256x256 kernel: vmcnt(0) + one barrier at the top of a step, the 8 DMA pieces of the next stage
 // issued in the MFMA gaps of this one, fragments rolling through registers behind counted lgkmcnt waits.
+// Tile order of the persistent 128x128 kernel (and of the tail launch that finishes its last round): tile index t -> origin.
+// XCD-contiguous (workgroups b and b + 8 share an XCD, so consecutive tile indices of one XCD walk one tile group) and grouped
+// column-major inside groups of GM row tiles, so that an XCD's L2 sees few distinct weight / activation rows at a time.
+__device__ __forceinline__ void p8_tile_origin128(int t, int ntiles, int tiles_m, int tiles_n, int& m0, int& n0) {
+    const int xcd = t & 7, q = ntiles >> 3, rr = ntiles & 7;
+    const int idx = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
+    constexpr int GM = 4;
+    const int width = GM * tiles_n;
+    const int group = idx / width, first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_g = idx - group * width;
+    const int tn = in_g / gsz;
+    m0 = (first_m + (in_g - tn * gsz)) * 128;
+    n0 = tn * 128;
+}
+
 template <int ABL = 0, int TAG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
     constexpr int BM = 128, BN = 128, BK = 32;
@@ -948,18 +974,8 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto tile_origin = [&](int t, int& m0, int& n0) {
-        const int xcd = t & 7, q = ntiles >> 3, rr = ntiles & 7;
-        const int idx = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
-        constexpr int GM = 4;
-        const int width = GM * tiles_n;
-        const int group = idx / width, first_m = group * GM;
-        const int gsz = min(tiles_m - first_m, GM);
-        const int in_g = idx - group * width;
-        const int tn = in_g / gsz;
-        m0 = (first_m + (in_g - tn * gsz)) * BM;
-        n0 = tn * BN;
-    };
+    auto tile_origin = [&](int t, int& m0, int& n0) { p8_tile_origin128(t, ntiles, tiles_m, tiles_n, m0, n0); };
+    const int t_end = g.tile_end > 0 ? g.tile_end : ntiles;        // tail split: the rest is another launch's (kernels.h)
     auto set_src = [&](int m0, int n0) {
         const int grp = g.ngrp ? n0 / g.ngrp : 0;          // column group (kernels.h): global column indices stay, the bases move
         const long wgrp_off = grp ? (long)grp * (g.grpW - (long)g.ngrp * g.ldw) : 0;
@@ -982,7 +998,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
     };
 
     int t = blockIdx.x;
-    if (t >= ntiles) return;
+    if (t >= t_end) return;
     int m0, n0;
     tile_origin(t, m0, n0);
     set_src(m0, n0);
@@ -997,7 +1013,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         const int t_next = t + gridDim.x;
-        const bool has_next = t_next < ntiles;
+        const bool has_next = t_next < t_end;
         int nm0 = 0, nn0 = 0;
         if (has_next) tile_origin(t_next, nm0, nn0);
         for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -1087,7 +1103,14 @@ __global__ __launch_bounds__(256) void gemm_p8_sm_kernel(const GemmArgs g) {
         tn = in_g / gsz;
         tm = first_m + (in_g - tn * gsz);
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    int m0 = tm * BM, n0 = tn * BN;
+    if (BM == 64 && BN == 64 && g.tail_t0 > 0) {
+        // tail launch of the persistent 128x128 kernel: workgroup b = sub-tile (b & 3) of that kernel's tile tail_t0 + (b >> 2)
+        const int t128_n = (g.N + 127) / 128, t128_m = (g.M + 127) / 128;
+        p8_tile_origin128(g.tail_t0 + (blockIdx.x >> 2), t128_n * t128_m, t128_m, t128_n, m0, n0);
+        m0 += (blockIdx.x & 1) * 64;
+        n0 += ((blockIdx.x >> 1) & 1) * 64;
+    }
     const int nk_all = g.K / BK;   // split-K: this workgroup owns K tiles [kt0, kt0 + nk)
     const int kt0 = (int)((long)nk_all * blockIdx.y / g.splitk);
     const int nk = (int)((long)nk_all * (blockIdx.y + 1) / g.splitk) - kt0;
@@ -1273,8 +1296,13 @@ static bool epi_vec_host(const GemmArgs& g) {
     if (g.gate) bits |= (unsigned long long)g.ldg | ((unsigned long long)g.gate >> 2);
     return (bits & 3) == 0;
 }
-void launch_gemm_p8(const GemmArgs& g, hipStream_t s) {
-    if (g.M <= 0 || g.N <= 0) return;
+void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
+    if (g0.M <= 0 || g0.N <= 0) return;
+    // No range guard in the epilogues of the large-grid kernels (measured: 322 -> 313 TF/s on the wav2vec2 encoder with it): their P8
+    // results (q|k|v, FFN hidden) are consumed by the attention kernel and by the next GEMM + LayerNorm, an out-of-range value turns
+    // into inf / NaN there, and those producers (attention output, LayerNorm) carry the guard - one kernel later instead of in place.
+    GemmArgs g = g0;
+    if (getenv("ARTALK_P8_GUARD_BIG") == nullptr) g.status = nullptr;
     const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t256 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
     const int t256sq = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     int cfg = g.force_cfg;
@@ -1294,8 +1322,22 @@ void launch_gemm_p8(const GemmArgs& g, hipStream_t s) {
         default:
             if (cfg == 8 && g.force_cfg < 0 && g.splitk == 1 && persist && epi_vec_host(g) && (!g.graph_tag || t128 >= 1024)) {
                 // production choice: persistent, deferred epilogue (inside the captured AR/VAE body only for grids several rounds deep)
-                if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wgp_kernel<1>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, g);
-                else hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, g);
+                GemmArgs a = g;
+                const int rem = t128 % 512;
+                // tail split (tuning, off: ARTALK_P8_TAIL=n turns it on for last rounds of up to n tiles): the last, partly filled round
+                // finished by 64x64 sub-tiles.  Measured slower (encoder 43.4 -> 45.6 ms per step at 320): the workgroups of a partly
+                // filled round have their CU to themselves and finish early, while the extra launch pays its boundary and the small kernel's rate
+                static const int tail_max = getenv("ARTALK_P8_TAIL") ? atoi(getenv("ARTALK_P8_TAIL")) : 0;
+                const bool tail = t128 > 512 && rem > 0 && rem <= tail_max && g.ngrp == 0;
+                if (tail) a.tile_end = t128 - rem;
+                if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wgp_kernel<1>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, a);
+                else hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, a);
+                if (tail) {
+                    GemmArgs b = g;
+                    b.tail_t0 = t128 - rem;
+                    if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_sm_kernel<64, 64, 4, 1>), dim3(rem * 4, 1), dim3(256), 4 * 128 * 128, s, b);
+                    else hipLaunchKernelGGL((gemm_p8_sm_kernel<64, 64, 4, 0>), dim3(rem * 4, 1), dim3(256), 4 * 128 * 128, s, b);
+                }
             }
             else if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wg_kernel<0, 1>), dim3(t128, g.splitk), dim3(256), 2 * 256 * 128, s, g);
             else hipLaunchKernelGGL((gemm_p8_2wg_kernel<0, 0>), dim3(t128, g.splitk), dim3(256), 2 * 256 * 128, s, g);

@@ -49,8 +49,13 @@ struct GemmArgs {
     // shares A - weight rows at W + j*grpW, bias at bias + j*grpB, result columns at C + j*grpC (elements; ngrp % 128 == 0).
     // One launch then computes the same input through many layers' weights (the history K/V of all 12 AR blocks).
     int ngrp = 0; long grpW = 0, grpB = 0, grpC = 0;
+    // tail split of the persistent 128x128 kernel (launch_gemm_p8): it walks tiles [0, tile_end) of its (swizzled) tile order in
+    // whole rounds of 512 workgroups; the remaining tiles [tail_t0, ntiles) are cut into four 64x64 sub-tiles each and run by the
+    // small-grid kernel, so the last, partly filled round costs a quarter-tile's time instead of a whole tile's.  0 = unused.
+    int tile_end = 0, tail_t0 = 0;
     int force_cfg = -1;  // >= 0: tile configuration override (tuning/tests)
     int graph_tag = 0;   // 1 for launches inside the captured AR/VAE body (separate kernel symbol, same code)
+    int* status = nullptr;   // model status word: bit 3 is raised when a value leaves the range of the P8 format (c_p8 results, fp32 A split while staging)
 };
 void launch_gemm(const GemmArgs& g, hipStream_t s);
 void launch_splitk_reduce(const GemmArgs& g, hipStream_t s);   // epilogue pass of a split-K GEMM (g.splitk > 1)
@@ -60,7 +65,7 @@ bool splitk_reduce_ln_eligible(const GemmArgs& g, const LnArgs& ln);
 void launch_splitk_reduce_ln(const GemmArgs& g, const LnArgs& ln, hipStream_t s);
 int gemm_tile_count(const GemmArgs& g, bool f16s);             // output tiles of the configuration launch_gemm[_f16s] would pick
 // fp32-accurate GEMM on the fp16 matrix cores by operand splitting (gemm_f16s.hip)
-void launch_pack_split(const float* w, unsigned int* out, long n, bool is_weight, hipStream_t s);
+void launch_pack_split(const float* w, unsigned int* out, long n, bool is_weight, hipStream_t s, int* status = nullptr);
 bool gemm_f16s_eligible(const GemmArgs& g);
 int gemm_f16s_config(const GemmArgs& g);     // register-staged kernel: 0: 128x128, 1: 64x64
 void launch_gemm_f16s(const GemmArgs& g, hipStream_t s);
@@ -83,6 +88,11 @@ struct LnArgs {
     long ldm = 0; RowMap mmap = {INT_MAX, 0, 0};
     int M = 0, D = 0; float eps = 1e-5f; int act = ACT_NONE;
     int out_p8 = 0;   // 1: write Y in the P8 split format (consumer is a split GEMM); same row pitch as fp32
+    int* status = nullptr;   // out_p8: range guard (see GemmArgs::status)
+    // rows r with r % junk_period >= junk_from are layout padding (the per-chunk row stride of the wav2vec2 buffers exceeds the
+    // valid frames; their input is whatever an earlier launch left there and no valid row ever reads them): they are stored as
+    // zeros, which keeps everything computed from them finite and inside the P8 range, and are exempt from the range guard.
+    int junk_period = 0, junk_from = 0;
 };
 void launch_layernorm(const LnArgs& a, hipStream_t s);
 
@@ -99,6 +109,7 @@ struct AttnArgs {
     int out_p8 = 0;                                  // 1: write O in the P8 split format
     int split16 = 0;                                 // 1: fp16 operand-split MFMAs (f16x3 mode), 0: exact fp32 MFMAs
     int qkv_p8 = 0;                                  // 1 (with split16, no l2norm): Q, K, V rows are in the P8 split format (written so by the qkv GEMM)
+    int* status = nullptr;                           // out_p8: range guard (see GemmArgs::status)
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -107,10 +118,10 @@ void launch_attention(const AttnArgs& a, hipStream_t s);
 void launch_audio_normalize(const float* audio, const long* src_off, float* xnorm, int n_chunks, int n, hipStream_t s);
 // conv0 (Cin=1,k=10,s=5) + bias + LN(512, affine) + GELU(erf): xnorm [C, n] -> Y rows c*row_stride + t, t < T
 void launch_conv0(const float* xnorm, int n, const float* w /*[512,10]*/, const float* bias, const float* lnw,
-                  const float* lnb, float* Y, int n_chunks, int T, int row_stride, hipStream_t s, int out_p8 = 0);
+                  const float* lnb, float* Y, int n_chunks, int T, int row_stride, hipStream_t s, int out_p8 = 0, int* status = nullptr);
 // multi-scale adaptive average pooling 199 -> {1,5,25,50,100} followed by SiLU: X rows c*x_tstride + t -> Y rows c*181 + tok
 void launch_pool_silu(const float* X, int x_tstride, int T, float* Y, int n_chunks, const int* patch_nums, int n_lvls,
-                      int D, hipStream_t s, int out_p8 = 0);
+                      int D, hipStream_t s, int out_p8 = 0, int* status = nullptr);
 
 // ---- AR / VAE glue ----
 // level p: logits [B*pn, 64] -> bits[b, off..off+pn, 32]; fhat[b] += up(h_p); nextfeat[b, :pn[p+1], 32] = area(fhat) (p < 4)
@@ -152,6 +163,9 @@ void launch_flame_pose(const float* pose, float* rot, float* feat, int T, int ld
 void launch_flame_joints(const float* vs, const float* jreg, float* J, int T, int V, hipStream_t s);
 void launch_flame_skin(const float* vposed, const float* rot, const float* J, const int* parents, const float* weights, float* out,
                        int T, int V, float scale, hipStream_t s);
+// headroom audit: *slot = max(*slot, bits of max |x| * 16) over rows x cols (cols % 8 == 0) of a P8 (is_p8) or fp32 buffer
+void launch_absmax(const float* buf, int rows, int cols, long ld, int is_p8, unsigned int* slot, hipStream_t s, int junk_period = 0,
+                   int junk_from = 0);
 int init_ms_tables();    // uploads the (tiny) interpolation tables to the CURRENT device's __constant__ memory, once per device; 0 = ok
 
 }  // namespace artalk

@@ -85,6 +85,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
         for (int i = 0; i < NV; ++i) { const float d = v[rr][i] - mean; q += d * d; }
         const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + a.eps);
         float* y = a.Y + (long)row * a.ldy;
+        const bool junk = a.junk_period && row % a.junk_period >= a.junk_from;      // layout padding row: stored as zeros (kernels.h)
+        int* const status = junk ? nullptr : a.status;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int c = (i * 64 + lane) * VW;
@@ -94,10 +96,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
                 float t = (v[rr][i * VW + e] - mean) * rstd;
                 if (a.w) t = t * wv[i * VW + e] + bv[i * VW + e];
                 if (a.scale) t = t * (scv[i * VW + e] + 1.0f) + shv[i * VW + e];
-                o[e] = apply_act_rt(t, a.act);
+                o[e] = junk ? 0.f : apply_act_rt(t, a.act);
             }
             if (VW == 4 && a.out_p8) {
-                store_p8x4_pair(y, c, o[0], o[1], o[2], o[3]);      // c = 4 * (64 i + lane): adjacent lanes, adjacent runs
+                store_p8x4_pair(y, c, o[0], o[1], o[2], o[3], status);      // c = 4 * (64 i + lane): adjacent lanes, adjacent runs
             } else if (VW == 4) {
                 f32x4 t = {o[0], o[1], o[2], o[3]};
                 *reinterpret_cast<f32x4*>(y + c) = t;

@@ -55,7 +55,7 @@ void launch_audio_normalize(const float* audio, const long* src_off, float* xnor
 // 20 bytes of audio in, 2 KiB out per frame: store-bandwidth bound.
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn, int n, const float* __restrict__ w,
                                                     const float* __restrict__ bias, const float* __restrict__ lnw,
-                                                    const float* __restrict__ lnb, float* __restrict__ Y, int T, int row_stride, int out_p8) {
+                                                    const float* __restrict__ lnb, float* __restrict__ Y, int T, int row_stride, int* __restrict__ status, int out_p8) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.y;
     int ch[8];
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
         for (int j = 0; j < 8; ++j) o[j] = gelu_erf((v[j] - mean) * rstd * gw[j] + gb[j]);
         float* y = Y + ((long)c * row_stride + t) * 512;
         if (out_p8) {
-            store_p8x4(y, lane * 4, o[0], o[1], o[2], o[3]);
-            store_p8x4(y, 256 + lane * 4, o[4], o[5], o[6], o[7]);
+            store_p8x4(y, lane * 4, o[0], o[1], o[2], o[3], status);
+            store_p8x4(y, 256 + lane * 4, o[4], o[5], o[6], o[7], status);
         } else {
             f32x4 lo = {o[0], o[1], o[2], o[3]}, hi = {o[4], o[5], o[6], o[7]};
             *reinterpret_cast<f32x4*>(y + lane * 4) = lo;
@@ -105,16 +105,16 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
 }
 
 void launch_conv0(const float* xnorm, int n, const float* w, const float* bias, const float* lnw, const float* lnb,
-                  float* Y, int n_chunks, int T, int row_stride, hipStream_t s, int out_p8) {
+                  float* Y, int n_chunks, int T, int row_stride, hipStream_t s, int out_p8, int* status) {
     if (n_chunks <= 0) return;
-    hipLaunchKernelGGL(conv0_kernel, dim3(128, n_chunks), dim3(256), 0, s, xnorm, n, w, bias, lnw, lnb, Y, T, row_stride, out_p8);
+    hipLaunchKernelGGL(conv0_kernel, dim3(128, n_chunks), dim3(256), 0, s, xnorm, n, w, bias, lnw, lnb, Y, T, row_stride, status, out_p8);
 }
 
 // ------------------------------------------------------------------------------------------------
 struct PoolLevels { int n; int pn[8]; };
 
 __global__ __launch_bounds__(256) void pool_silu_kernel(const float* __restrict__ X, int x_tstride, int T, float* __restrict__ Y,
-                                                        PoolLevels lv, int ntok, int D, int out_p8) {
+                                                        PoolLevels lv, int ntok, int D, int out_p8, int* __restrict__ status) {
     const int tok = blockIdx.x, c = blockIdx.y;
     int p = 0, i = tok;
     while (i >= lv.pn[p]) { i -= lv.pn[p]; ++p; }
@@ -128,19 +128,19 @@ __global__ __launch_bounds__(256) void pool_silu_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = silu(s[e] / inv);
         float* yrow = Y + ((long)c * ntok + tok) * D;
-        if (out_p8) store_p8x4(yrow, d, o[0], o[1], o[2], o[3]);
+        if (out_p8) store_p8x4(yrow, d, o[0], o[1], o[2], o[3], status);
         else *reinterpret_cast<f32x4*>(yrow + d) = o;
     }
 }
 
 void launch_pool_silu(const float* X, int x_tstride, int T, float* Y, int n_chunks, const int* patch_nums, int n_lvls, int D,
-                      hipStream_t s, int out_p8) {
+                      hipStream_t s, int out_p8, int* status) {
     if (n_chunks <= 0) return;
     PoolLevels lv;
     lv.n = n_lvls;
     int ntok = 0;
     for (int i = 0; i < 8; ++i) { lv.pn[i] = i < n_lvls ? patch_nums[i] : 1 << 30; if (i < n_lvls) ntok += patch_nums[i]; }
-    hipLaunchKernelGGL(pool_silu_kernel, dim3(ntok, n_chunks), dim3(256), 0, s, X, x_tstride, T, Y, lv, ntok, D, out_p8);
+    hipLaunchKernelGGL(pool_silu_kernel, dim3(ntok, n_chunks), dim3(256), 0, s, X, x_tstride, T, Y, lv, ntok, D, out_p8, status);
 }
 
 }  // namespace artalk

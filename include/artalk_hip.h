@@ -151,6 +151,12 @@ int artalk_set_precision(artalk_model* m, int mode);
  * Bits 16-23 / 24-31, when non-zero, override the split-K policy in units of 16 tiles (split when a GEMM has fewer output
  * tiles than the first, aim for the second; defaults 192 / 384 measured best). */
 int artalk_set_graphs(artalk_model* m, int enable);
+/* Headroom audit of the f16x3 operand format: while enabled every artalk_infer runs without graphs and records, for each
+ * producer of a P8 operand (LayerNorm outputs, GEMM results written in P8, attention outputs, ...), max |x| * 16 - the value that
+ * must stay below fp16's 65504.  artalk_get_audit synchronises and returns the number of sites; names_buf receives the site
+ * names NUL-separated, values[i] the maximum seen at site i since the audit was switched on (tools/p8_headroom.py). */
+int artalk_set_audit(artalk_model* m, int enable);
+int artalk_get_audit(artalk_model* m, char* names_buf, int buf_len, float* values, int max_n);
 /* Overlapped schedule of artalk_infer (default 0 = off; when on, used from 8 clips up): wav2vec2 runs chunk index by chunk
  * index on a low-priority stream of the library while the latency-bound AR/VAE body of the previous chunk index runs on the
  * caller's stream.  Measured +3.5 % at batch 32 (both sides slow each other down); 0 = all of wav2vec2 first. */

@@ -32,6 +32,7 @@ def test_config4_demo_wavs_batch32_styled(precision):
     m.set_precision(precision)
     try:
         outs, bits, hist = _run_set(m, audios, styles)          # ONE inference_batch call, ragged, per-clip style
+        assert m._precision == precision and m.status() == 0, "the call tripped the range guard and was redone in f32 mode"
     finally:
         m.set_precision("f32")
     # clip 5 (jp2, style 205): the reference's own margin at history decision (1, token 79, bit 25) is |z| = 1.2e-7, and the GPU
@@ -82,6 +83,7 @@ def test_config2_batch32_synthetic_10s(precision):
     m.set_precision(precision)
     try:
         outs, bits, hist = _run_set(m, audios, styles)
+        assert m._precision == precision and m.status() == 0, "the call tripped the range guard and was redone in f32 mode"
         worst = 0.0
         for i, c in enumerate(clips):                      # seeds 0..7 against the reference itself
             good, n, err = assert_clip_parity(f"cfg2 clip {i}", precision, outs[i], bits[i], hist[i], c["out"], c["bits"], c["hist_bits"],

@@ -39,6 +39,7 @@ def test_against_reference_golden(case, precision):
     audio, style = golden_inputs(g, sd)
     out = m.inference_batch([audio], [style], return_aux=True)[0].cpu().numpy()
     aux = m.last_aux
+    assert m._precision == precision and m.status() == 0, "the call tripped the range guard and was redone in f32 mode"
     m.set_precision("f32")
     # wav2vec2 features (third-party arithmetic pinned by the golden slice)
     w2v = aux["w2v"].cpu().numpy()
@@ -223,6 +224,11 @@ def test_f16x3_overflow_falls_back_to_f32():
     m.set_precision("f32")
     want = m.inference_batch([audio])[0]
     m.set_precision("f16x3")
+    # the producer itself reports the range violation (status bit 3), not only the NaN that reaches a decision later
+    m.check_finite = False
+    m.inference_batch([audio])
+    assert m.status() & 8, "the LayerNorm that produced the out-of-range P8 operand did not raise status bit 3"
+    m.check_finite = True
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         got = m.inference_batch([audio])[0]

@@ -114,7 +114,9 @@ def test_gemm_p8_dma_pipeline_and_producers():
     out = torch.full((M, N), float("nan"), device="cuda")
     # LDS-DMA kernels 128x128 / 256x256 / two-workgroup / 256x128, register-staged 128x128 and 64x64, the small-grid LDS-DMA kernel
     # (64x64, 128x64, 128x128; 20 | 3 << 8 = split-K 3; 8 | 3 << 8 = the two-workgroup kernel with split-K 3; 9 = its persistent form with the deferred epilogue), all fed with the P8 activation
-    for cfg in (2, 7, 8, 9, 6, 0, 1, 20, 21, 22, 20 | (3 << 8), 21 | (5 << 8), 8 | (3 << 8)):
+    # 99 = the engine's own choice: here the persistent kernel over one whole round of 512 tiles + the tail split (the last 8 of
+    # the 520 tiles as 32 sub-tiles of the small-grid kernel); 23-26: the deep-ring small-grid configurations with split-K
+    for cfg in (2, 7, 8, 9, 99, 6, 0, 1, 20, 21, 22, 20 | (3 << 8), 21 | (5 << 8), 8 | (3 << 8), 23 | (4 << 8), 24 | (6 << 8), 25 | (3 << 8), 26 | (4 << 8)):
         out.fill_(float("nan"))
         assert L.artalk_op_gemm_f16s_packed(_p(Ap), 1, K, _p(Wp), _p(db), _p(out), M, N, K, 0, cfg, None) == 0
         torch.cuda.synchronize()
@@ -122,7 +124,7 @@ def test_gemm_p8_dma_pipeline_and_producers():
         assert err < 2e-6, (cfg, err)
     # small ragged shapes of the AR scale steps through the small-grid kernel (M = 80 / 400 rows, K = 1024 here)
     for Ms in (80, 400):
-        for cfg in (20, 21, 20 | (4 << 8), 9, 8):     # 9 / 8: the large-grid kernels on a grid smaller than the chip (one tile per workgroup)
+        for cfg in (20, 21, 20 | (4 << 8), 23 | (8 << 8), 24 | (2 << 8), 9, 8):     # 9 / 8: the large-grid kernels on a grid smaller than the chip (one tile per workgroup)
             o2 = torch.full((Ms, N), float("nan"), device="cuda")
             assert L.artalk_op_gemm_f16s_packed(_p(Ap), 1, K, _p(Wp), _p(db), _p(o2), Ms, N, K, 0, cfg, None) == 0
             torch.cuda.synchronize()

@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Headroom of the f16x3 operand format ("P8": f16(16 x) + residual) on every golden input -> profiles/r02_p8_headroom.json.
+
+For each producer site of a P8 operand (artalk_set_audit) the largest |x| * 16 seen over all fixtures, and the factor left to
+fp16's 65504.  The weights are synthetic (no checkpoint is available offline), so this documents the mechanism and the margin
+on the synthetic model; a real checkpoint is audited by the same command, and at run time a value beyond the range raises bit 3
+of the status word where it is produced (the model then re-runs in exact-f32 mode and stays there).
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+from artalk_amd import capi                                                       # noqa: E402
+from conftest import (clip_set_inputs, get_gpu_model, get_state_dict, golden_inputs, load_clip_set, load_golden)   # noqa: E402
+
+CASES = ["full_10s_s0", "full_10s_s1_style", "full_4s_s2", "full_5p5s_s3_style", "full_demo_eng1", "full_demo_eng2", "full_demo_cn1",
+         "full_demo_cn2", "full_demo_jp1", "full_demo_jp2"]
+
+
+def read_audit(m):
+    L = capi.lib()
+    buf = C.create_string_buffer(1 << 16)
+    vals = (C.c_float * 1024)()
+    n = L.artalk_get_audit(m._h, buf, len(buf), vals, 1024)
+    assert n >= 0
+    names = buf.raw.split(b"\0")[:n]
+    return {nm.decode(): float(vals[i]) for i, nm in enumerate(names)}
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "profiles", "r02_p8_headroom.json")
+    cfg, sd = get_state_dict("full")
+    m = get_gpu_model("full")
+    m.set_precision("f16x3")
+    L = capi.lib()
+    assert L.artalk_set_audit(m._h, 1) == 0
+    n_clips = 0
+    for case in CASES:
+        g = load_golden(case)
+        audio, style = golden_inputs(g, sd)
+        m.inference_batch([audio], [style])
+        n_clips += 1
+    for name in ("full_cfg4_demo32", "full_cfg2_synth8"):
+        clips = load_clip_set(name)
+        audios, styles = clip_set_inputs(clips, sd)
+        m.inference_batch(audios, styles)
+        n_clips += len(clips)
+    table = read_audit(m)
+    status = m.status()
+    L.artalk_set_audit(m._h, 0)
+    rows = sorted(table.items(), key=lambda t: -t[1])
+    worst = rows[0]
+    res = {
+        "what": "max |x| * 16 per producer site of a P8 (f16x3) operand over all golden inputs; limit 65504 (fp16 max)",
+        "weights": "deterministic synthetic weights (seed 1234), reference motion statistics", "clips": n_clips,
+        "status_word": status, "limit": 65504.0,
+        "worst_site": worst[0], "worst_value": worst[1], "min_headroom_factor": 65504.0 / max(worst[1], 1e-30),
+        "sites": {k: {"max_abs_x16": v, "headroom_factor": (65504.0 / v if v > 0 else None)} for k, v in rows},
+    }
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(f"{len(rows)} sites over {n_clips} clips; worst {worst[0]} = {worst[1]:.1f} (headroom x{res['min_headroom_factor']:.0f}); status {status}")
+    for k, v in rows[:12]:
+        print(f"  {k:50s} {v:10.2f}")
+
+
+if __name__ == "__main__":
+    main()
