@@ -157,29 +157,41 @@ void launch_ar_bits_next(const float* logits, uint8_t* bits, float* fhat, float*
 // ------------------------------------------------------------------------------------------------
 // X[b*xrows + xoff + i, :] = We * feat[b, i, :] + be + pos[i, :]      for i < n          (grid.x = i)
 // X[b*xrows + 0, :]        = style_cond[b, :] + pos0[:]                for blockIdx.x == n (only if style_cond)
+// A workgroup embeds VQ_TOK tokens of one clip: a thread keeps one weight row (32 floats) in registers and applies it to all the
+// tokens (features in LDS), so the 98 KB weight matrix is read once per 16 tokens instead of once per token (69 -> ~10 us for
+// the 180 history tokens of 16 clips).  The dot product runs over c in the same order as before: results are bit-identical.
+constexpr int VQ_TOK = 16;
 __global__ __launch_bounds__(256) void vq_embed_kernel(const float* __restrict__ feat, int n, const float* __restrict__ We,
                                                        const float* __restrict__ be, const float* __restrict__ pos,
                                                        float* __restrict__ X, int xrows, int xoff,
                                                        const float* __restrict__ style_cond, const float* __restrict__ pos0, int E) {
-    __shared__ float f[CD];
-    const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    if (i == n) {
+    __shared__ float f[VQ_TOK][CD];
+    const int i0 = blockIdx.x * VQ_TOK, b = blockIdx.y, tid = threadIdx.x;
+    if (blockIdx.x == 0 && style_cond) {
         for (int e = tid; e < E; e += 256) X[((long)b * xrows) * E + e] = style_cond[(long)b * E + e] + pos0[e];
-        return;
     }
-    if (tid < CD) f[tid] = feat[((long)b * n + i) * CD + tid];
+    const int nt = min(VQ_TOK, n - i0);
+    for (int idx = tid; idx < nt * CD; idx += 256) f[idx / CD][idx % CD] = feat[((long)b * n + i0) * CD + idx];
     __syncthreads();
     for (int e = tid; e < E; e += 256) {
-        const float* w = We + (long)e * CD;
-        float acc = 0.f;
+        float w[CD];
 #pragma unroll
-        for (int c = 0; c < CD; ++c) acc = fmaf(w[c], f[c], acc);
-        X[((long)b * xrows + xoff + i) * E + e] = (acc + be[e]) + pos[(long)i * E + e];
+        for (int c4 = 0; c4 < CD / 4; ++c4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(We + (long)e * CD + 4 * c4);
+            w[4 * c4] = t[0]; w[4 * c4 + 1] = t[1]; w[4 * c4 + 2] = t[2]; w[4 * c4 + 3] = t[3];
+        }
+        const float bias = be[e];
+        for (int t = 0; t < nt; ++t) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CD; ++c) acc = fmaf(w[c], f[t][c], acc);
+            X[((long)b * xrows + xoff + i0 + t) * E + e] = (acc + bias) + pos[(long)(i0 + t) * E + e];
+        }
     }
 }
 void launch_vq_embed(const float* feat, int n, const float* We, const float* be, const float* pos, float* X, int xrows,
                      int xoff, const float* style_cond, const float* pos0, int B, hipStream_t s) {
-    hipLaunchKernelGGL(vq_embed_kernel, dim3(n + (style_cond ? 1 : 0), B), dim3(256), 0, s, feat, n, We, be, pos, X, xrows, xoff,
+    hipLaunchKernelGGL(vq_embed_kernel, dim3((n + VQ_TOK - 1) / VQ_TOK, B), dim3(256), 0, s, feat, n, We, be, pos, X, xrows, xoff,
                        style_cond, pos0, 768);
 }
 

@@ -629,8 +629,12 @@ void run_vae_stack(artalk_model* m, const VAESide& S, int B, int T, int split, h
         launch_attention(a, s);
         audit(m, an + ".attn_out", w.vatt, M, H, H, p8, s);
         linear(m, w.vatt, H, L.out_w, L.out_b, w.vh, H, M, H, H, ACT_NONE, w.vh, s, AP);
-        audit(m, an + ".residual(fp32 A of mlp.0)", w.vh, M, H, H, false, s);
-        linear(m, w.vh, H, L.m1_w, L.m1_b, w.vmlp, F, M, F, H, ACT_GELU_TANH, nullptr, s, p8 ? LF_C_P8 : 0);   // A = residual stream (fp32)
+        // the MLP reads the residual stream itself (no LayerNorm in front of it, bitwise_vae.py:139-145).  In f16x3 mode one split pass
+        // writes it in P8 so that the GEMM can stage it by LDS-DMA (the register-staged kernel on fp32 rows took 36 us at
+        // M = 6400, the pass + the small-grid kernel 4 + 15)
+        if (p8) launch_pack_split(w.vh, reinterpret_cast<unsigned int*>(w.vln), (long)M * H, false, s, w.status);
+        audit(m, an + ".residual", p8 ? w.vln : w.vh, M, H, H, p8, s);
+        linear(m, p8 ? w.vln : w.vh, H, L.m1_w, L.m1_b, w.vmlp, F, M, F, H, ACT_GELU_TANH, nullptr, s, p8 ? (LF_A_P8 | LF_C_P8) : 0);
         audit(m, an + ".mlp_hidden", w.vmlp, M, F, F, p8, s);
         linear(m, w.vmlp, F, L.m2_w, L.m2_b, w.vh, H, M, H, F, ACT_NONE, w.vh, s, AP);
     }
