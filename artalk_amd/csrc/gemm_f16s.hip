@@ -685,10 +685,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
 // Tile order of the persistent 128x128 kernel (and of the tail launch that finishes its last round): tile index t -> origin.
 // XCD-contiguous (workgroups b and b + 8 share an XCD, so consecutive tile indices of one XCD walk one tile group) and grouped
 // column-major inside groups of GM row tiles, so that an XCD's L2 sees few distinct weight / activation rows at a time.
-__device__ __forceinline__ void p8_tile_origin128(int t, int ntiles, int tiles_m, int tiles_n, int& m0, int& n0) {
+__device__ __forceinline__ void p8_tile_origin128(int t, int ntiles, int tiles_m, int tiles_n, int& m0, int& n0, int GM = 4) {
     const int xcd = t & 7, q = ntiles >> 3, rr = ntiles & 7;
     const int idx = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
-    constexpr int GM = 4;
     const int width = GM * tiles_n;
     const int group = idx / width, first_m = group * GM;
     const int gsz = min(tiles_m - first_m, GM);
@@ -974,7 +973,8 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto tile_origin = [&](int t, int& m0, int& n0) { p8_tile_origin128(t, ntiles, tiles_m, tiles_n, m0, n0); };
+    const int gm_rows = g.tile_gm > 0 ? g.tile_gm : 4;
+    auto tile_origin = [&](int t, int& m0, int& n0) { p8_tile_origin128(t, ntiles, tiles_m, tiles_n, m0, n0, gm_rows); };
     const int t_end = g.tile_end > 0 ? g.tile_end : ntiles;        // tail split: the rest is another launch's (kernels.h)
     auto set_src = [&](int m0, int n0) {
         const int grp = g.ngrp ? n0 / g.ngrp : 0;          // column group (kernels.h): global column indices stay, the bases move
@@ -1323,6 +1323,8 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
             if (cfg == 8 && g.force_cfg < 0 && g.splitk == 1 && persist && epi_vec_host(g) && (!g.graph_tag || t128 >= 1024)) {
                 // production choice: persistent, deferred epilogue (inside the captured AR/VAE body only for grids several rounds deep)
                 GemmArgs a = g;
+                static const int tile_gm = getenv("ARTALK_P8_GM") ? atoi(getenv("ARTALK_P8_GM")) : 0;      // tuning: row tiles per XCD tile group
+                a.tile_gm = tile_gm;
                 const int rem = t128 % 512;
                 // tail split (tuning, off: ARTALK_P8_TAIL=n turns it on for last rounds of up to n tiles): the last, partly filled round
                 // finished by 64x64 sub-tiles.  Measured slower (encoder 43.4 -> 45.6 ms per step at 320): the workgroups of a partly
@@ -1349,7 +1351,8 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
 // AdaLN table: 354 vs 329 and 330 vs 306 TF/s), loses on the encoder GEMMs (profiles/r01_gemm_f16s_bench.log).
 int gemm_p8_variant(const GemmArgs& g) {
     const long t256sq = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
-    return (t256sq >= 2560 && g.N % 256 == 0 && g.ngrp == 0) ? 1 : 0;      // column groups: the 128x128 kernels only
+    static const long min256 = getenv("ARTALK_P8_256_MIN") ? atol(getenv("ARTALK_P8_256_MIN")) : 2560;      // tuning
+    return (t256sq >= min256 && g.N % 256 == 0 && g.ngrp == 0) ? 1 : 0;      // column groups: the 128x128 kernels only
 }
 bool gemm_p8_eligible(const GemmArgs& g) {
     return g.Wp != nullptr && g.a_packed && g.amode == 0 && g.batch == 1 && g.splitk == 1 && g.K % 32 == 0 && (g.lda % 8) == 0 &&

@@ -53,6 +53,7 @@ struct GemmArgs {
     // whole rounds of 512 workgroups; the remaining tiles [tail_t0, ntiles) are cut into four 64x64 sub-tiles each and run by the
     // small-grid kernel, so the last, partly filled round costs a quarter-tile's time instead of a whole tile's.  0 = unused.
     int tile_end = 0, tail_t0 = 0;
+    int tile_gm = 0;     // tuning: row tiles per XCD tile group of the persistent kernel (0 = 4)
     int force_cfg = -1;  // >= 0: tile configuration override (tuning/tests)
     int graph_tag = 0;   // 1 for launches inside the captured AR/VAE body (separate kernel symbol, same code)
     int* status = nullptr;   // model status word: bit 3 is raised when a value leaves the range of the P8 format (c_p8 results, fp32 A split while staging)

@@ -1,19 +1,31 @@
 # Collects everything kept under profiles/ for a round: run on the GPU box as
-#   gpurun -- 'bash tools/collect_profiles.sh'   (outputs under gpurun_out/r01/, then copied into profiles/ by hand)
+#   gpurun -- 'bash tools/collect_profiles.sh r02'   (outputs under gpurun_out/<round>/, then copied into profiles/ by hand)
 set -e
+R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01
+O=gpurun_out/$R
 rm -rf $O && mkdir -p $O
 echo "== unprofiled default bench"
-timeout -k 10 500 python bench.py 2>$O/bench.err | tail -1 > $O/bench_line.json
+timeout -k 10 500 python bench.py --steps 20 --warmup 5 2>$O/bench.err | tail -1 > $O/bench_line.json
 cut -c1-400 $O/bench_line.json
 echo "== kernel trace f16x3"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_f16x3 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-mode > $O/kt_f16x3.log 2>&1
 python tools/summarize_profile.py stats $O/kt_f16x3 $O/f16x3_kernel_stats.csv > /dev/null
 python tools/summarize_profile.py shapes $O/kt_f16x3 $O/f16x3_launch_shapes.csv > /dev/null
 find $O/kt_f16x3 -name "*kernel_trace.csv" -delete
+echo "== kernel trace, one clip group: the AR/VAE body per scale step"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_b32 -- python3 bench.py --steps 2 --warmup 2 --branches 1 --resident --no-cpu-baseline --no-alt-mode > $O/kt_b32.log 2>&1
+python tools/summarize_profile.py levels $O/kt_b32 $O/body_levels_b32.csv > /dev/null
+find $O/kt_b32 -name "*kernel_trace.csv" -delete
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_b16 -- python3 bench.py --steps 2 --warmup 2 --batch 16 --branches 1 --resident --no-cpu-baseline --no-alt-mode > $O/kt_b16.log 2>&1
+python tools/summarize_profile.py levels $O/kt_b16 $O/body_levels_b16.csv > /dev/null
+find $O/kt_b16 -name "*kernel_trace.csv" -delete
+echo "== roctx ranges (marker trace)"
+timeout -k 10 300 rocprofv3 --marker-trace --output-format csv -d $O/mk -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-mode > $O/mk.log 2>&1 || true
+python tools/summarize_profile.py markers $O/mk $O/roctx_ranges.csv > /dev/null || true
+find $O/mk -name "*marker_api_trace.csv" -delete || true
 echo "== kernel trace f32"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_f32 -- python3 bench.py --steps 5 --warmup 2 --precision f32 --no-cpu-baseline > $O/kt_f32.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_f32 -- python3 bench.py --steps 3 --warmup 2 --precision f32 --no-cpu-baseline --no-alt-mode > $O/kt_f32.log 2>&1
 python tools/summarize_profile.py stats $O/kt_f32 $O/f32_kernel_stats.csv > /dev/null
 find $O/kt_f32 -name "*kernel_trace.csv" -delete
 echo "== pmc fetch"
@@ -23,9 +35,8 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 python tools/summarize_profile.py pmc $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json | head -12
 find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete
 echo "== gemm microbenchmarks"
-GEMM_VARIANTS="1:1,2:1,7:1,8:1" GEMM_ONLY="w2v qkv,w2v out,w2v ff1,w2v ff2,conv1,ada" timeout -k 10 200 python tools/gemm_f16s_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_f16s_bench.log
-GEMM_VARIANTS="1:1,20:1,21:1" GEMM_ONLY="g qkv p4,g proj p4,g ffn1 p4,g ffn2 p4,g qkv p2,g proj p2,g ffn1 p2,g ffn2 p2,g qkv p1,g ffn2 p1,g hist kv" timeout -k 10 200 python tools/gemm_f16s_bench.py 2>&1 | grep -v amdgpu.ids >> $O/gemm_f16s_bench.log
-for c in 16 17 18; do echo "-- STAMP_CFG=$c" >> $O/gemm_p8_stamps.log; STAMP_CFG=$c timeout -k 10 100 python tools/gemm_p8_stamps.py 2>&1 | grep -v amdgpu.ids >> $O/gemm_p8_stamps.log; done
+GEMM_GRAPH=0 GEMM_VARIANTS="1:1,2:1,7:1,8:1,99:1" GEMM_ONLY="w2v qkv,w2v out,w2v ff1,w2v ff2,conv1,ada" timeout -k 10 200 python tools/gemm_f16s_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_f16s_bench.log
 timeout -k 10 100 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > $O/attn_bench.log
-timeout -k 10 60 python tools/mfma_subnormal_probe.py > $O/mfma_subnormal_probe.log 2>&1
+echo "== P8 headroom"
+timeout -k 10 200 python tools/p8_headroom.py $O/p8_headroom.json 2>&1 | grep -v amdgpu.ids | tail -14
 ls $O

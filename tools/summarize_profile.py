@@ -116,6 +116,21 @@ def levels(d, out):
     print(open(out).read())
 
 
+def markers(d, out):
+    """rocprofv3 --marker-trace: host-side roctx ranges of the path (artalk.* : enqueue time of each kernel group)."""
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    f = find(d, "*marker_api_trace.csv")
+    for r in csv.DictReader(open(f)):
+        name = r.get("Function") or r.get("Marker_Name") or r.get("Name") or "?"
+        agg[name][0] += 1
+        agg[name][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    with open(out, "w") as fo:
+        fo.write("range,count,total_host_ms,avg_host_us\n")
+        for k, v in sorted(agg.items(), key=lambda t: -t[1][1]):
+            fo.write(f"\"{k}\",{v[0]},{v[1] / 1e3:.3f},{v[1] / v[0]:.1f}\n")
+    print(open(out).read())
+
+
 def pmc(fd, wd, out):
     res = collections.defaultdict(dict)
     for tag, d in (("FETCH_SIZE", fd), ("WRITE_SIZE", wd)):
@@ -143,7 +158,9 @@ def pmc(fd, wd, out):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "levels":
+    if sys.argv[1] == "markers":
+        markers(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "levels":
         levels(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "shapes":
         shapes(sys.argv[2], sys.argv[3])
