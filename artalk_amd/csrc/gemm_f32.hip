@@ -385,8 +385,68 @@ __global__ __launch_bounds__(256) void mfma_f32_peak_kernel(float* out, int iter
         for (int e = 0; e < 16; ++e) s += acc[i][e];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
-// returns FLOPs issued by one launch; nacc = independent accumulators per wave (1 = one dependent chain, like the 64x64 GEMM)
+// fp16 matrix cores, register-only, on non-trivial data: the rate (and the clock the chip holds: out[...] also receives the
+// in-kernel clock = d s_memtime / d s_memrealtime x 100 MHz) that bounds the f16x3 split GEMM.  SHAPE 0: v_mfma_f32_32x32x16_f16
+// (4 accumulators of 16 registers), 1: v_mfma_f32_16x16x32_f16 (16 accumulators of 4 registers): equal cycles per flop.
+typedef _Float16 pk_h8 __attribute__((ext_vector_type(8)));
+typedef float pk_f4 __attribute__((ext_vector_type(4)));
+template <int SHAPE>
+__global__ __launch_bounds__(256) void mfma_f16_peak_kernel(float* out, int iters, float seed) {
+    const int lane = threadIdx.x & 63;
+    pk_h8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(seed * (float)(lane + 1 + e) * 0.013f); b[e] = (_Float16)(0.5f - seed * (float)(63 - lane + e) * 0.011f); }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    float sum = 0.f;
+    if (SHAPE == 0) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+            }
+            a[it & 7] = -a[it & 7]; b[(it + 3) & 7] = b[(it + 3) & 7] * (_Float16)0.999f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sum += acc[i][e];
+    } else {
+        pk_f4 acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const pk_f4 z = {0.f, 0.f, 0.f, 0.f}; acc[i] = z; }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+            }
+            a[it & 7] = -a[it & 7]; b[(it + 3) & 7] = b[(it + 3) & 7] * (_Float16)0.999f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += acc[i][e];
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float v = sum;
+    if (threadIdx.x == 0) v = (float)((double)(c1 - c0) / (double)(r1 - r0) * 0.1);     // GHz (s_memrealtime ticks at 100 MHz)
+    out[blockIdx.x * 256 + threadIdx.x] = v;
+}
+// returns FLOPs issued by one launch; nacc = independent accumulators per wave (1 = one dependent chain, like the 64x64 GEMM);
+// nacc 16 / 17: the fp16 kernels above (32x32x16 / 16x16x32)
 double launch_mfma_f32_peak(float* out, int blocks, int iters, int nacc, hipStream_t s) {
+    if (nacc == 16 || nacc == 17) {
+        if (nacc == 16) hipLaunchKernelGGL(mfma_f16_peak_kernel<0>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
+        else hipLaunchKernelGGL(mfma_f16_peak_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
+        // per iteration and wave: 32 MFMAs of 32x32x16 (32768 flops each) or 64 of 16x16x32 (16384 flops each)
+        return (double)blocks * 4 * iters * 32.0 * (32.0 * 32 * 16 * 2);
+    }
     if (nacc == 1) hipLaunchKernelGGL(mfma_f32_peak_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
     else hipLaunchKernelGGL(mfma_f32_peak_kernel<4>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
     return (double)blocks * 4 /*waves*/ * iters * 32.0 /*mfma per iter*/ * (32.0 * 32 * 2 * 2);

@@ -32,6 +32,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything i
 GFLOP_PER_FRAME = 2.159          # algorithmic work with KV cache, BASELINE.md section 3
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
+SUSTAINED_F16_MFMA_TFLOPS = 1780.0   # measured: register-only v_mfma_f32_32x32x16_f16 loop on non-trivial data holds a 1.75 GHz clock (profiles/r02_mfma_f16_peak.log)
 PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"      # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
 MODES = {
     # precision -> (dtype string, dominant kernel symbol prefix in the PMC file, description, peak TF/s of ALGORITHMIC flops, note)
@@ -268,6 +269,9 @@ def main():
         roofline = {
             "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(dom_tflops / peak, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": kdesc, "peak_note": peak_note,
+            "frac_of_sustained": (round(dom_tflops / (SUSTAINED_F16_MFMA_TFLOPS / 3.0), 4) if args.precision == "f16x3" else None),
+            "sustained_note": ("a register-only fp16 MFMA loop sustains 1780 TF/s on this chip (clock 1.75 GHz under that load, "
+                               "profiles/r02_mfma_f16_peak.log): 593 TF/s of algorithmic flops for the 3-product split") if args.precision == "f16x3" else None,
             "launches": int(prof["dom_launches"]), "avg_launch_ms": round(prof["dom_ms"] / max(prof["dom_launches"], 1), 4),
             "share_of_step_ms": round(prof["dom_ms"], 2),
         }

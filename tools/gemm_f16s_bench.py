@@ -40,7 +40,7 @@ for name, M, N, K in SHAPES:
     ref = A[:256].double() @ W.double().t() + b.double()
     line = f"{name:12s} M={M:6d} N={N:5d} K={K:4d} "
     for cfg, apk in variants:
-        if 2 <= (cfg & 0xff) < 20 and (cfg & 0xff) != 8 and M < 3000: continue
+        if 2 <= (cfg & 0xff) < 20 and (cfg & 0xff) not in (2, 3, 5, 8) and M < 3000: continue
         best = 1e9
         n = 3 if M * N * K > 1e11 else (10 if ROT == 1 else ROT)
         a = Ap if apk else A
