@@ -1171,7 +1171,7 @@ int artalk_set_graphs(artalk_model* m, int enable) {
     if (!m) return ARTALK_EINVAL;
     m->use_graphs = (enable & 0xff) != 0;
     const int br = (enable >> 8) & 0xff;          // tuning: enable | (branches << 8) forces 1 / 2 / 4 concurrent clip groups
-    if (br == 0 || br == 1 || br == 2 || br == 4) m->branches = br; else return ARTALK_EINVAL;
+    if (br >= 0 && br <= 4) m->branches = br; else return ARTALK_EINVAL;
     if ((enable >> 16) & 0xffff) {                // tuning: split-K thresholds, (tiles/16) << 16 | (target/16) << 24
         m->splitk_tiles = ((enable >> 16) & 0xff) * 16; m->splitk_target = ((enable >> 24) & 0xff) * 16;
     }
