@@ -110,6 +110,7 @@ struct artalk_model {
     unsigned int* audit_vals = nullptr;            // device, kAuditSlots floats (as bits)
     std::vector<std::string> audit_names;
     std::map<std::string, int> audit_index;
+    int posconv_lds = 1;              // tuning (ARTALK_POSCONV_LDS): LDS-resident positional convolution in f16x3 mode
     int hist_kv_batched = 1;          // tuning (ARTALK_HIST_KV_BATCHED): history K/V of all blocks as one GEMM over column groups
     int sm_split_768 = 1;             // tuning (ARTALK_SM_SPLIT768): split K = 768 GEMMs of the smallest scale steps too (deep-ring kernels)
     int stream_B = 0;                 // streams opened by artalk_stream_begin (history lives in the workspace)
@@ -528,15 +529,23 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     layernorm(src, dst, m->fp_lnw, m->fp_lnb, M, CD, c.w2v_ln_eps, ACT_NONE, s, p8, w.status, JP, JF);
     audit(m, "w2v.feature_projection.ln", dst, M, CD, CD, p8, s, JP, JF);
     linear(m, dst, CD, m->fp_w, m->fp_b, w.h0, Hs, M, Hs, CD, ACT_NONE, nullptr, s, AP);
-    // positional conv embedding (hf:360-368): h1 = h0 + gelu(groupconv(h0) + b)   (fp32 kernel: gathers the padded window)
+    // positional conv embedding (hf:360-368): h1 = h0 + gelu(groupconv(h0) + b)
     {
         const int cg = Hs / c.w2v_pos_groups;
         GemmArgs g;
-        g.A = w.h0; g.lda = Hs; g.amode = 1; g.pc_T = m->Tw; g.pc_tstride = m->Ts; g.pc_pad = c.w2v_pos_kernel / 2; g.pc_cin = cg;
-        g.W = m->pos_w; g.ldw = (long)cg * c.w2v_pos_kernel; g.bias = m->pos_b; g.C = w.h1; g.ldc = Hs; g.R = w.h0; g.ldr = Hs;
-        g.M = M; g.N = cg; g.K = cg * c.w2v_pos_kernel; g.act = ACT_GELU_ERF;
-        g.batch = c.w2v_pos_groups; g.sA = cg; g.sW = (long)cg * cg * c.w2v_pos_kernel; g.sBias = cg; g.sC = cg; g.sR = cg;
-        gemm(m, g, s);
+        g.A = w.h0; g.lda = Hs; g.W = m->pos_w; g.ldw = (long)cg * c.w2v_pos_kernel; g.bias = m->pos_b; g.C = w.h1; g.ldc = Hs; g.R = w.h0; g.ldr = Hs;
+        g.M = M; g.act = ACT_GELU_ERF;
+        if (p8 && m->posconv_lds && cg == 64 && c.w2v_pos_kernel == 128 && c.w2v_pos_groups == 16 && m->Ts <= 256) {
+            // f16x3 mode: one workgroup per (chunk, group) with the chunk's input window resident in LDS (posconv_p8_kernel)
+            g.N = Hs; g.K = cg * c.w2v_pos_kernel; g.Wp = packed_of(m, m->pos_w); g.status = w.status;
+            launch_posconv_p8(g, n, m->Tw, m->Ts, s);
+        } else {
+            // grouped GEMM over grid.z whose A operand gathers the zero-padded window (amode 1)
+            g.amode = 1; g.pc_T = m->Tw; g.pc_tstride = m->Ts; g.pc_pad = c.w2v_pos_kernel / 2; g.pc_cin = cg;
+            g.N = cg; g.K = cg * c.w2v_pos_kernel;
+            g.batch = c.w2v_pos_groups; g.sA = cg; g.sW = (long)cg * cg * c.w2v_pos_kernel; g.sBias = cg; g.sC = cg; g.sR = cg;
+            gemm(m, g, s);
+        }
     }
     float* h = w.h1;
     const int nh = c.w2v_heads, hd = Hs / nh;
@@ -982,6 +991,7 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
     m->cfg = c; m->device = device_id;
     if (const char* e = getenv("ARTALK_SM_SPLIT768")) m->sm_split_768 = atoi(e);
     if (const char* e = getenv("ARTALK_HIST_KV_BATCHED")) m->hist_kv_batched = atoi(e);
+    if (const char* e = getenv("ARTALK_POSCONV_LDS")) m->posconv_lds = atoi(e);
     // conv stack geometry: T_l valid frames; row stride S_l per chunk with S_l = 2*S_{l+1} so that one GEMM covers all chunks
     int T = kSamplesPerChunk;
     for (int i = 0; i < c.w2v_n_conv; ++i) { T = (T - c.w2v_conv_kernel[i]) / c.w2v_conv_stride[i] + 1; m->conv_T[i] = T; }

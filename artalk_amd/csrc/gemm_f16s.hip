@@ -1260,6 +1260,203 @@ __global__ __launch_bounds__(256) void gemm_p8_sm_kernel(const GemmArgs g) {
             epilogue_tile32(g, epi, m0 + wm * (BM / 2) + i * 32 + r, n0 + wn * (BN / 2) + j * 32, h, acc[i][j]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Grouped positional convolution of wav2vec2 (hf:360-368: Conv1d(1024, 1024, k = 128, padding 64, groups 16) + GELU, added to its
+// input) as a split GEMM whose activation operand never leaves the CU.  One workgroup = one 4-second chunk x one group of 64
+// channels: the 200 output frames need input frames -64 .. 262 of the same 64 channels, i.e. a 327-row window of 256 bytes per row
+// in the P8 format.  The window is split once into LDS (zero rows outside the chunk = the convolution's padding) and the operand of
+// tap j is simply the window shifted by j rows; only the weights (2 MB per group, shared by all chunks of the group and kept in
+// the XCD's L2 by the block -> (chunk, group) map) stream through a 4-stage LDS-DMA ring of 8 KB stages.  24 MFMAs per wave per
+// 32-deep K step against 8 KB of DMA: bound by the matrix cores (the register-staged kernel that gathered the window from
+// global memory for every tap ran at 160 TF/s, 2.0 ms per step).
+//   8 waves, 4 (rows) x 2 (columns): wave tile 64 x 32 = 2 accumulators; 8 row tiles cover 256 rows (200 used)
+//   window rows have a pitch of 272 bytes (256 + 16): the 16 lanes a ds_read_b128 serves together read 16 consecutive rows at one
+//   chunk, i.e. 16 different bank quads, without any swizzle - so a lane needs ONE address register per K step (its row at this
+//   tap) and every fragment is that register plus a compile-time offset (channel half, k block, hi / lo, second row tile);
+//   the address arithmetic of an XOR-swizzled window cost more vector issue slots than the MFMAs leave free
+constexpr int PC_WIN_ROWS = 384, PC_PITCH = 272, PC_WIN_BYTES = PC_WIN_ROWS * PC_PITCH, PC_STAGE = 64 * 128, PC_STAGES = 4;
+template <int OFF>
+__device__ __forceinline__ f16x8 lds_read128_big(unsigned addr) {      // offset up to 65535 (the DS instructions' 16-bit immediate)
+    f16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int TAG>
+__global__ __launch_bounds__(512) void posconv_p8_kernel(const GemmArgs g, int T, int Ts) {
+    constexpr int CG = 64, KT = 128, PAD = 64, NSTEP = KT * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
+    unsigned char* win = smem_p8;
+    unsigned char* ring = smem_p8 + PC_WIN_BYTES;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // blocks b and b + 8 share an XCD: XCD x gets groups 2x and 2x + 1 only (4 MB of weights, its L2)
+    const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3;
+    const int grp = xcd * 2 + (jj & 1), c = jj >> 1;
+    const long row0 = (long)c * Ts;
+
+    // ---- weight ring: piece = 8 rows x 128 B; wave w (of 8) owns rows 8w .. 8w+7 of the 64 output channels ----
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const unsigned char* wsrc;
+    {
+        const int rw = wave * 8 + prow;
+        wsrc = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)(grp * CG + rw) * g.ldw) * 4 + ((pchunk ^ ((rw >> 1) & 7)) << 4);
+    }
+    auto issue_stage = [&](int ks, int buf) {
+        unsigned char* dst = ring + buf * PC_STAGE + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (long)ks * 128),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+#pragma unroll
+    for (int st = 0; st < PC_STAGES - 1; ++st) issue_stage(st, st);
+
+    // ---- window: rows w = ts + 64 for ts in [-64, 320); valid ts in [0, T) come from X (fp32, split here), the rest are zeros ----
+    for (int idx = tid; idx < PC_WIN_ROWS * 8; idx += 512) {
+        const int w = idx >> 3, g8 = idx & 7;
+        const int ts = w - PAD;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (ts >= 0 && ts < T) {
+            const float* xp = g.A + (row0 + ts) * g.lda + grp * CG + g8 * 8;
+            a = *reinterpret_cast<const f32x4*>(xp);
+            b = *reinterpret_cast<const f32x4*>(xp + 4);
+            p8_guard(g.status, a[0], a[1], a[2], a[3]);
+            p8_guard(g.status, b[0], b[1], b[2], b[3]);
+        }
+        u32x2 h0, l0, h1, l1;
+        split_f32x4(a, kActScale, h0, l0);
+        split_f32x4(b, kActScale, h1, l1);
+        const u32x4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
+        unsigned char* rowp = win + w * PC_PITCH + g8 * 32;
+        *reinterpret_cast<u32x4*>(rowp) = hi;
+        *reinterpret_cast<u32x4*>(rowp + 16) = lo;
+    }
+
+    // 8 waves = 4 (rows) x 2 (columns), wave tile 64 x 32 = 2 accumulators: two waves per SIMD, so one wave's barrier / wait / issue
+    // gaps run under the other's MFMAs (with 4 waves of 128 x 32 the kernel took 1.41 ms against an MFMA floor of 0.67)
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_p8;
+    const unsigned ring0 = lds0 + PC_WIN_BYTES;
+    unsigned w_addr[2][2];              // [kb][hi/lo]: LDS address inside ring stage 0 (stage b = + b * PC_STAGE, an immediate)
+    {
+        const int wrow = wn * 32 + r, wkey = (wrow >> 1) & 7;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int lo = 0; lo < 2; ++lo) w_addr[kb][lo] = ring0 + wrow * 128 + ((((kb * 2 + h) * 2 + lo) ^ wkey) << 4);
+    }
+    // window address of this lane's activation row (tile 0) at tap 0, channel half 0, k block 0, hi: + tap * PC_PITCH per tap;
+    // offsets: channel half 128, k block 64, lo 16, second row tile 32 * PC_PITCH
+    const unsigned a_lane = lds0 + (wm * 64 + r) * PC_PITCH + h * 32;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    // Fragments are software-pipelined ACROSS the per-step barrier: the weight fragments of step ks+1 and the activation fragments
+    // of its tile 0 are read during step ks.  Legal because the barrier at the top of step ks already guarantees that stage ks+1
+    // has landed (every wave waited for its own piece of it first).  At most 12 LDS reads in flight (lgkmcnt is a 4-bit counter).
+    // The loop is unrolled by 4 = ring depth, so ring buffer, channel half and register set are compile-time.
+    f16x8 bh[2][2], bl[2][2];           // weights [register set][kb]
+    f16x8 a0h[2][2], a0l[2][2];         // activations of tile 0 [register set][kb]
+    f16x8 a1h[2], a1l[2];               // activations of tile 1 [kb]
+    auto read_w = [&](auto buf_tag, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value, OFF = decltype(buf_tag)::value * PC_STAGE;
+        bh[S][0] = lds_read128_big<OFF>(w_addr[0][0]); bl[S][0] = lds_read128_big<OFF>(w_addr[0][1]);
+        bh[S][1] = lds_read128_big<OFF>(w_addr[1][0]); bl[S][1] = lds_read128_big<OFF>(w_addr[1][1]);
+    };
+    auto read_a0 = [&](unsigned abase, auto half_tag, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value, HO = decltype(half_tag)::value * 128;
+        a0h[S][0] = lds_read128_big<HO>(abase);      a0l[S][0] = lds_read128_big<HO + 16>(abase);
+        a0h[S][1] = lds_read128_big<HO + 64>(abase); a0l[S][1] = lds_read128_big<HO + 80>(abase);
+    };
+    auto read_a1 = [&](unsigned abase, auto half_tag) {
+        constexpr int HO = decltype(half_tag)::value * 128 + 32 * PC_PITCH;
+        a1h[0] = lds_read128_big<HO>(abase);      a1l[0] = lds_read128_big<HO + 16>(abase);
+        a1h[1] = lds_read128_big<HO + 64>(abase); a1l[1] = lds_read128_big<HO + 80>(abase);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+    __syncthreads();                    // the window is complete (ds writes of every wave)
+    wait_vmcnt<2>();                    // stage 0 landed (stages 1, 2: one piece each per wave, may be in flight)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_w(I0{}, I0{});
+    read_a0(a_lane, I0{}, I0{});
+    // one K step (J = ks & 3): on entry the reads of W and of tile 0 (register set J & 1) of this step are in flight, in that order
+    auto kstep = [&](int ks, auto j_tag) {
+        constexpr int J = decltype(j_tag)::value, S = J & 1;
+        using SET = std::integral_constant<int, S>;
+        using NSET = std::integral_constant<int, 1 - S>;
+        using HALF = std::integral_constant<int, J & 1>;
+        using NHALF = std::integral_constant<int, (J + 1) & 1>;
+        using NBUF = std::integral_constant<int, (J + 1) & 3>;
+        const unsigned abase = a_lane + (ks >> 1) * PC_PITCH;
+        // stage ks+1 has landed when at most the youngest stage (one piece) is still in flight
+        if (ks + 2 < NSTEP) wait_vmcnt<1>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // stage ks+1 landed for every wave; every wave is done with stage ks-1, whose buffer is refilled now
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + PC_STAGES - 1 < NSTEP) {
+            issue_stage(ks + PC_STAGES - 1, (J + PC_STAGES - 1) & (PC_STAGES - 1));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_a1(abase, HALF{});
+        wait_lgkmcnt<4>();              // W and tile 0 are in registers
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[S][kb], a0h[S][kb], acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[S][kb], a0h[S][kb], acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[S][kb], a0l[S][kb], acc[0], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 1 < NSTEP) {           // next step's weights and tile 0 into the other register set
+            read_w(NBUF{}, NSET{});
+            read_a0(a_lane + ((ks + 1) >> 1) * PC_PITCH, NHALF{}, NSET{});
+            wait_lgkmcnt<8>();          // tile 1
+        } else {
+            wait_lgkmcnt<0>();
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[S][kb], a1h[kb], acc[1], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[S][kb], a1h[kb], acc[1], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[S][kb], a1l[kb], acc[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int ks = 0; ks < NSTEP; ks += 4) {
+        kstep(ks, I0{});
+        kstep(ks + 1, I1{});
+        kstep(ks + 2, I2{});
+        kstep(ks + 3, I3{});
+    }
+
+    const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] *= kOutScale;
+        const int t = wm * 64 + 32 * i + r;                  // frame inside the chunk; rows >= Ts belong to nobody
+        const int row = t < Ts ? (int)(row0 + t) : g.M;
+        epilogue_tile32(g, epi, row, grp * CG + wn * 32, h, acc[i]);
+    }
+}
+// g: A = input hidden states (fp32, row stride lda, rows chunk * Ts + t), Wp = packed weights [1024][128 * 64] (ldw = 8192),
+// bias, C / R = output / residual (row stride ldc / ldr), act, M = n_chunks * Ts, N = 1024
+void launch_posconv_p8(const GemmArgs& g, int n_chunks, int T, int Ts, hipStream_t s) {
+    if (n_chunks <= 0) return;
+    const size_t lds = PC_WIN_BYTES + PC_STAGES * PC_STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {      // more than the default 64 KB of dynamic LDS
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&posconv_p8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((posconv_p8_kernel<0>), dim3(n_chunks * 16), dim3(512), lds, s, g, T, Ts);
+}
+
 template <int BM, int BN, int STAGES>
 static void launch_p8_sm_cfg(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
