@@ -1349,6 +1349,118 @@ __global__ __launch_bounds__(512) void posconv_p8_kernel(const GemmArgs g, int T
     // offsets: channel half 128, k block 64, lo 16, second row tile 32 * PC_PITCH
     const unsigned a_lane = lds0 + (wm * 64 + r) * PC_PITCH + h * 32;
 
+    if constexpr (TAG == 1) {
+        // ---- experiment (ARTALK_POSCONV_MFMA16=1): the same wave tile on v_mfma_f32_16x16x32_f16 (8 accumulators of 4 registers).
+        // Equal cycles per flop, but the chip holds a higher clock under this shape (profiles/r02_mfma_f16_peak.log) ----
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        const int r16 = lane & 15, gq = lane >> 4;
+        unsigned w16[2][2];             // [n tile][hi/lo]
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int wrow = wn * 32 + nt * 16 + r16, wkey = (wrow >> 1) & 7;
+#pragma unroll
+            for (int lo = 0; lo < 2; ++lo) w16[nt][lo] = ring0 + wrow * 128 + (((gq * 2 + lo) ^ wkey) << 4);
+        }
+        const unsigned a16 = lds0 + (wm * 64 + r16) * PC_PITCH + gq * 32;     // + tap * PC_PITCH; tile mt: + 16 mt PC_PITCH; half: + 128; lo: + 16
+        f32x4v c16[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { const f32x4v z = {0.f, 0.f, 0.f, 0.f}; c16[i][j] = z; }
+        f16x8 wh[2][2], wl[2][2];       // [set][n tile]
+        f16x8 p01h[2][2], p01l[2][2];   // activations of m tiles 0, 1: [set][tile]
+        f16x8 p23h[2], p23l[2];         // m tiles 2, 3
+        auto rd_w = [&](auto buf_tag, auto set_tag) {
+            constexpr int S = decltype(set_tag)::value, OFF = decltype(buf_tag)::value * PC_STAGE;
+            wh[S][0] = lds_read128_big<OFF>(w16[0][0]); wl[S][0] = lds_read128_big<OFF>(w16[0][1]);
+            wh[S][1] = lds_read128_big<OFF>(w16[1][0]); wl[S][1] = lds_read128_big<OFF>(w16[1][1]);
+        };
+        auto rd_p01 = [&](unsigned abase, auto half_tag, auto set_tag) {
+            constexpr int S = decltype(set_tag)::value, HO = decltype(half_tag)::value * 128;
+            p01h[S][0] = lds_read128_big<HO>(abase);                 p01l[S][0] = lds_read128_big<HO + 16>(abase);
+            p01h[S][1] = lds_read128_big<HO + 16 * PC_PITCH>(abase); p01l[S][1] = lds_read128_big<HO + 16 * PC_PITCH + 16>(abase);
+        };
+        auto rd_p23 = [&](unsigned abase, auto half_tag) {
+            constexpr int HO = decltype(half_tag)::value * 128;
+            p23h[0] = lds_read128_big<HO + 32 * PC_PITCH>(abase); p23l[0] = lds_read128_big<HO + 32 * PC_PITCH + 16>(abase);
+            p23h[1] = lds_read128_big<HO + 48 * PC_PITCH>(abase); p23l[1] = lds_read128_big<HO + 48 * PC_PITCH + 16>(abase);
+        };
+        using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+        using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+        __syncthreads();
+        wait_vmcnt<2>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        rd_w(J0{}, J0{});
+        rd_p01(a16, J0{}, J0{});
+        auto kstep16 = [&](int ks, auto j_tag) {
+            constexpr int J = decltype(j_tag)::value, S = J & 1;
+            using NSET = std::integral_constant<int, 1 - S>;
+            using HALF = std::integral_constant<int, J & 1>;
+            using NHALF = std::integral_constant<int, (J + 1) & 1>;
+            using NBUF = std::integral_constant<int, (J + 1) & 3>;
+            const unsigned abase = a16 + (ks >> 1) * PC_PITCH;
+            if (ks + 2 < NSTEP) wait_vmcnt<1>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + PC_STAGES - 1 < NSTEP) {
+                issue_stage(ks + PC_STAGES - 1, (J + PC_STAGES - 1) & (PC_STAGES - 1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rd_p23(abase, HALF{});
+            wait_lgkmcnt<4>();
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    c16[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[S][nt], p01h[S][mt], c16[mt][nt], 0, 0, 0);
+                    c16[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[S][nt], p01h[S][mt], c16[mt][nt], 0, 0, 0);
+                    c16[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[S][nt], p01l[S][mt], c16[mt][nt], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < NSTEP) {
+                rd_w(NBUF{}, NSET{});
+                rd_p01(a16 + ((ks + 1) >> 1) * PC_PITCH, NHALF{}, NSET{});
+                wait_lgkmcnt<8>();
+            } else {
+                wait_lgkmcnt<0>();
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    c16[2 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[S][nt], p23h[mt], c16[2 + mt][nt], 0, 0, 0);
+                    c16[2 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[S][nt], p23h[mt], c16[2 + mt][nt], 0, 0, 0);
+                    c16[2 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[S][nt], p23l[mt], c16[2 + mt][nt], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int ks = 0; ks < NSTEP; ks += 4) {
+            kstep16(ks, J0{});
+            kstep16(ks + 1, J1{});
+            kstep16(ks + 2, J2{});
+            kstep16(ks + 3, J3{});
+        }
+        // epilogue: lane (r16, gq) of tile (mt, nt) holds frame wm*64 + 16 mt + r16, channels n0 + 16 nt + 4 gq .. + 3
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int t = wm * 64 + 16 * mt + r16;
+            if (t >= Ts) continue;
+            const long row = row0 + t;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int col = grp * CG + wn * 32 + 16 * nt + 4 * gq;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + col);
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(g.R + row * g.ldr + col);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = gelu_erf(c16[mt][nt][e] * kOutScale + bv[e]) + rv[e];
+                *reinterpret_cast<f32x4*>(g.C + row * g.ldc + col) = o;
+            }
+        }
+        return;
+    }
+
     f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1454,7 +1566,9 @@ void launch_posconv_p8(const GemmArgs& g, int n_chunks, int T, int Ts, hipStream
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&posconv_p8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((posconv_p8_kernel<0>), dim3(n_chunks * 16), dim3(512), lds, s, g, T, Ts);
+    static const int mfma16 = getenv("ARTALK_POSCONV_MFMA16") ? atoi(getenv("ARTALK_POSCONV_MFMA16")) : 0;      // experiment, see the kernel
+    if (mfma16) hipLaunchKernelGGL((posconv_p8_kernel<1>), dim3(n_chunks * 16), dim3(512), lds, s, g, T, Ts);
+    else hipLaunchKernelGGL((posconv_p8_kernel<0>), dim3(n_chunks * 16), dim3(512), lds, s, g, T, Ts);
 }
 
 template <int BM, int BN, int STAGES>
