@@ -122,6 +122,10 @@ __device__ __forceinline__ EpiCtx make_epi(const GemmArgs& g, const float* bias,
     x.vec = (bits & 3) == 0;     // every row start and every run of 4 columns is 16-byte aligned
     return x;
 }
+// P8OK = false (the exact-fp32 kernels, which never produce a P8 result) compiles the split / guard paths out: with them in, the
+// 128x128 fp32 kernel went from 116 to 216 registers + scratch and the f32 mode from 227 to 665 ms per step.
+// GUARD = false (the large-grid kernels): no range guard in this epilogue (gemm_f16s.hip, launch_gemm_p8).
+template <bool P8OK = true, bool GUARD = true>
 __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx& x, int row, int col0, int h, f32x16& v) {   // v is clobbered
     const bool rok = row < g.M;
     const long crow = rok ? map_row(g.cmap, row) : 0;
@@ -143,8 +147,8 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
                 v[4 * q + e] = t + rv[e];
             }
         }
-        if (g.c_p8) {   // N % 8 == 0.  Pairs of 8-column groups (k, k+1): lanes h=0 end up with all of group k, lanes h=1 with group k+1
-            if (rok) {
+        if (P8OK && g.c_p8) {   // N % 8 == 0.  Pairs of 8-column groups (k, k+1): lanes h=0 end up with all of group k, lanes h=1 with group k+1
+            if (GUARD && rok) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (col0 + 8 * q + 4 * h < g.N) p8_guard(g.status, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
@@ -197,8 +201,8 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
             float t = apply_act_rt(v[e] + (x.bias ? x.bias[col] : 0.f), g.act);
             if (gp) t *= gp[col];
             if (rp) t += rp[col];
-            if (g.c_p8) {
-                p8_guard(g.status, t, 0.f, 0.f, 0.f);
+            if (P8OK && g.c_p8) {
+                if (GUARD) p8_guard(g.status, t, 0.f, 0.f, 0.f);
                 _Float16* o = reinterpret_cast<_Float16*>(x.C + crow * g.ldc + (col & ~7));
                 _Float16 hh, ll;
                 split_f16(t * kActScale, hh, ll);
@@ -212,6 +216,7 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
 }
 // Store-only form of epilogue_tile32 for a tile whose bias is already added and that has no gate / residual, every lane valid and
 // the 16-byte path available (the deferred epilogue of gemm_p8_2wgp_kernel): activation, then exactly 4 store instructions.
+template <bool GUARD = true>
 __device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* C, int row, int col0, int h, f32x16& v) {
     const long crow = map_row(g.cmap, row);
     if (g.act != ACT_NONE) {
@@ -219,7 +224,7 @@ __device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* 
         for (int e = 0; e < 16; ++e) v[e] = apply_act_rt(v[e], g.act);
     }
     if (g.c_p8) {
-        p8_guard16(g.status, v);
+        if (GUARD) p8_guard16(g.status, v);
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
             unsigned int w[2][4];
@@ -256,6 +261,7 @@ __device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* 
 // epilogue_row4: one lane owns 4 consecutive columns (col % 4 == 0) of one row; needs x.vec (16-byte aligned rows, N % 4 == 0).
 // For a P8 result adjacent lanes (col, col+4 of one 8-group) trade halves so that each writes one 16-byte hi or lo chunk; all 64
 // lanes must be active when it is called.
+template <bool GUARD = true>
 __device__ __forceinline__ void epilogue_row4(const GemmArgs& g, const EpiCtx& x, int row, int col, f32x4 v) {
     const bool ok = row < g.M && col < g.N;
     const long crow = ok ? map_row(g.cmap, row) : 0;
@@ -270,7 +276,7 @@ __device__ __forceinline__ void epilogue_row4(const GemmArgs& g, const EpiCtx& x
         v[e] = t + rv[e];
     }
     if (g.c_p8) {
-        if (ok) p8_guard(g.status, v[0], v[1], v[2], v[3]);
+        if (GUARD && ok) p8_guard(g.status, v[0], v[1], v[2], v[3]);
         f16x4_t hh, ll;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { _Float16 a, c; split_f16(v[e] * kActScale, a, c); hh[e] = a; ll[e] = c; }
@@ -310,7 +316,7 @@ __device__ __forceinline__ void epilogue_wave_lds(const GemmArgs& g, const EpiCt
 #pragma unroll
     for (int it = 0; it < 32 * NI / RPI; ++it) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(lds + (it * RPI + rr) * PITCH + cc);
-        epilogue_row4(g, x, row0 + it * RPI + rr, col0 + cc, v);
+        epilogue_row4<false>(g, x, row0 + it * RPI + rr, col0 + cc, v);      // (only the 256x256 large-grid kernel comes through here)
     }
 }
 

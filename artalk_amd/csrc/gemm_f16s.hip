@@ -468,7 +468,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) epilogue_tile32(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * (32 * TN) + j * 32, h, acc[i][j]);
+            for (int j = 0; j < TN; ++j) epilogue_tile32<true, false>(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * (32 * TN) + j * 32, h, acc[i][j]);
     }
     if constexpr (ABL == 6) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
             constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
-            epilogue_tile32(g, epi, m0 + wm * 128 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);
+            epilogue_tile32<true, false>(g, epi, m0 + wm * 128 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);
         };
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
         for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
         if constexpr (ABL == 7) { asm volatile("" ::"v"(acc[i][j])); return; }     // timing ablation: no epilogue at all
         if (P) partial_tile32(g, P, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);     // raw sums: splitk_reduce_kernel finishes
-        else epilogue_tile32(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);
+        else epilogue_tile32<true, false>(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);
     };
     {
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -966,10 +966,10 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
         substep(kt_issue, buf, sb, issue_tag, I1{}, I1{});
         if (dq >= 0) {
             const int row0 = pm0 + wm * 64 + r, col0 = pn0 + wn * 64;
-            if (dq == 0) epilogue_tile32_store(g, pC, row0, col0, h, keep[0][0]);
-            else if (dq == 1) epilogue_tile32_store(g, pC, row0, col0 + 32, h, keep[0][1]);
-            else if (dq == 2) epilogue_tile32_store(g, pC, row0 + 32, col0, h, keep[1][0]);
-            else epilogue_tile32_store(g, pC, row0 + 32, col0 + 32, h, keep[1][1]);
+            if (dq == 0) epilogue_tile32_store<false>(g, pC, row0, col0, h, keep[0][0]);
+            else if (dq == 1) epilogue_tile32_store<false>(g, pC, row0, col0 + 32, h, keep[0][1]);
+            else if (dq == 2) epilogue_tile32_store<false>(g, pC, row0 + 32, col0, h, keep[1][0]);
+            else epilogue_tile32_store<false>(g, pC, row0 + 32, col0 + 32, h, keep[1][1]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) epilogue_tile32(g, e2, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, keep[i][j]);
+                    for (int j = 0; j < 2; ++j) epilogue_tile32<true, false>(g, e2, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, keep[i][j]);
                 // a full fp32 tile issued exactly 16 store instructions behind the next tile's first stage (P8 results and
                 // partial tiles: wait for everything)
                 behind = (full && !g.c_p8) ? 16 : 0;
@@ -1064,10 +1064,10 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
     }
     if (pending) {
         const int row0 = pm0 + wm * 64 + r, col0 = pn0 + wn * 64;
-        epilogue_tile32_store(g, pC, row0, col0, h, keep[0][0]);
-        epilogue_tile32_store(g, pC, row0, col0 + 32, h, keep[0][1]);
-        epilogue_tile32_store(g, pC, row0 + 32, col0, h, keep[1][0]);
-        epilogue_tile32_store(g, pC, row0 + 32, col0 + 32, h, keep[1][1]);
+        epilogue_tile32_store<false>(g, pC, row0, col0, h, keep[0][0]);
+        epilogue_tile32_store<false>(g, pC, row0, col0 + 32, h, keep[0][1]);
+        epilogue_tile32_store<false>(g, pC, row0 + 32, col0, h, keep[1][0]);
+        epilogue_tile32_store<false>(g, pC, row0 + 32, col0 + 32, h, keep[1][1]);
     }
 }
 
@@ -1609,11 +1609,12 @@ static bool epi_vec_host(const GemmArgs& g) {
 }
 void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
     if (g0.M <= 0 || g0.N <= 0) return;
-    // No range guard in the epilogues of the large-grid kernels (measured: 322 -> 313 TF/s on the wav2vec2 encoder with it): their P8
-    // results (q|k|v, FFN hidden) are consumed by the attention kernel and by the next GEMM + LayerNorm, an out-of-range value turns
-    // into inf / NaN there, and those producers (attention output, LayerNorm) carry the guard - one kernel later instead of in place.
+    // No range guard in the epilogues of the large-grid kernels (compiled out: epilogue_tile32<.., GUARD = false>; with it the dominant
+    // kernel lost registers to it): their P8 results (q|k|v, FFN hidden) are consumed by the attention kernel and by the next GEMM +
+    // LayerNorm, an out-of-range value turns into inf / NaN there, and those producers (attention output, LayerNorm) carry the
+    // guard - one kernel later instead of in place.
     GemmArgs g = g0;
-    if (getenv("ARTALK_P8_GUARD_BIG") == nullptr) g.status = nullptr;
+    g.status = nullptr;
     const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t256 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
     const int t256sq = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     int cfg = g.force_cfg;

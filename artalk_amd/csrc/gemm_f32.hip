@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) epilogue_tile32(g, epi, m0 + wm * (BM / WM) + i * 32 + r, n0 + wn * (BN / WN) + j * 32, h, acc[i][j]);
+        for (int j = 0; j < TN; ++j) epilogue_tile32<false>(g, epi, m0 + wm * (BM / WM) + i * 32 + r, n0 + wn * (BN / WN) + j * 32, h, acc[i][j]);
 }
 
 template <int BM, int BN, int WM, int WN, int BK = 32>
