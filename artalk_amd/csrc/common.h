@@ -38,6 +38,45 @@ __device__ __forceinline__ float apply_act_rt(float x, int act) {
     }
 }
 
+// The same for the 16 values a lane holds of a 32x32 MFMA sub-tile: ONE (wave-uniform) switch around the loops, so that a kernel
+// carries each activation's code once per call site instead of once per element behind a branch.
+
+__device__ __forceinline__ void apply_act16(f32x16& v, int act) {
+    switch (act) {
+        case ACT_GELU_ERF:
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = gelu_erf(v[e]);
+            break;
+        case ACT_GELU_TANH:
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = gelu_tanh(v[e]);
+            break;
+        case ACT_LEAKY02:
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+            break;
+        default: break;
+    }
+}
+
+__device__ __forceinline__ void apply_act4(f32x4& v, int act) {
+    switch (act) {
+        case ACT_GELU_ERF:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            break;
+        case ACT_GELU_TANH:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+            break;
+        case ACT_LEAKY02:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+            break;
+        default: break;
+    }
+}
+
 // ---- "P8" split format (gemm_f16s.hip): an operand x is first scaled by a power of two S (activations kActScale, weights
 // kWScale), then every 8 consecutive elements of a row become 32 bytes [8 x f16 hi][8 x f16 lo] with hi = f16(S x) and
 // lo = f16(S x - hi) (UNSCALED residual; gfx950's f16 MFMA honours subnormal inputs - tools/mfma_subnormal_probe.py - so a
@@ -132,6 +171,7 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
     const float* gp = (g.gate && rok) ? g.gate + (long)map_row(g.gmap, row) * g.ldg : nullptr;
     const float* rp = (x.R && rok) ? x.R + crow * g.ldr : nullptr;
     if (x.vec) {
+        f32x4 act_gv[4], act_rv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = col0 + 8 * q + 4 * h;
@@ -140,12 +180,29 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
             if (x.bias && ok) b = *reinterpret_cast<const f32x4*>(x.bias + c);
             if (gp && ok) gv = *reinterpret_cast<const f32x4*>(gp + c);
             if (rp && ok) rv = *reinterpret_cast<const f32x4*>(rp + c);
+            if (g.act == ACT_NONE) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = apply_act_rt(v[4 * q + e] + b[e], g.act);
-                if (g.gate) t *= gv[e];
-                v[4 * q + e] = t + rv[e];
+                for (int e = 0; e < 4; ++e) {
+                    float t = v[4 * q + e] + b[e];
+                    if (g.gate) t *= gv[e];
+                    v[4 * q + e] = t + rv[e];
+                }
+            } else {      // (no launch combines an activation with a gate or a residual, but the order is kept: act(x + b) * gate + res)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] += b[e];
+                act_gv[q] = gv; act_rv[q] = rv;
             }
+        }
+        if (g.act != ACT_NONE) {
+            apply_act16(v, g.act);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = v[4 * q + e];
+                    if (g.gate) t *= act_gv[q][e];
+                    v[4 * q + e] = t + act_rv[q][e];
+                }
         }
         if (P8OK && g.c_p8) {   // N % 8 == 0.  Pairs of 8-column groups (k, k+1): lanes h=0 end up with all of group k, lanes h=1 with group k+1
             if (GUARD && rok) {
@@ -219,10 +276,7 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
 template <bool GUARD = true>
 __device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* C, int row, int col0, int h, f32x16& v) {
     const long crow = map_row(g.cmap, row);
-    if (g.act != ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = apply_act_rt(v[e], g.act);
-    }
+    apply_act16(v, g.act);
     if (g.c_p8) {
         if (GUARD) p8_guard16(g.status, v);
 #pragma unroll
@@ -262,16 +316,20 @@ __device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* 
 // For a P8 result adjacent lanes (col, col+4 of one 8-group) trade halves so that each writes one 16-byte hi or lo chunk; all 64
 // lanes must be active when it is called.
 template <bool GUARD = true>
-__device__ __forceinline__ void epilogue_row4(const GemmArgs& g, const EpiCtx& x, int row, int col, f32x4 v) {
+__device__ __forceinline__ void epilogue_row4(const GemmArgs& g, const EpiCtx& x, int row, int col, f32x4 v, const f32x4* bpre = nullptr) {
     const bool ok = row < g.M && col < g.N;
     const long crow = ok ? map_row(g.cmap, row) : 0;
     f32x4 b = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f}, rv = {0.f, 0.f, 0.f, 0.f};
-    if (x.bias && ok) b = *reinterpret_cast<const f32x4*>(x.bias + col);
+    if (bpre) b = *bpre;
+    else if (x.bias && ok) b = *reinterpret_cast<const f32x4*>(x.bias + col);
     if (g.gate && ok) gv = *reinterpret_cast<const f32x4*>(g.gate + (long)map_row(g.gmap, row) * g.ldg + col);
     if (x.R && ok) rv = *reinterpret_cast<const f32x4*>(x.R + crow * g.ldr + col);
 #pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += b[e];
+    apply_act4(v, g.act);
+#pragma unroll
     for (int e = 0; e < 4; ++e) {
-        float t = apply_act_rt(v[e] + b[e], g.act);
+        float t = v[e];
         if (g.gate) t *= gv[e];
         v[e] = t + rv[e];
     }
@@ -313,10 +371,15 @@ __device__ __forceinline__ void epilogue_wave_lds(const GemmArgs& g, const EpiCt
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int rr = lane / LPR, cc = (lane % LPR) * 4;
-#pragma unroll
+    // a lane's columns are the same in every iteration: its bias run is fetched once, before the first store (vmcnt counts loads and
+    // stores together in issue order, so a load inside the loop queues behind the previous iterations' stores)
+    f32x4 bpre = {0.f, 0.f, 0.f, 0.f};
+    if (x.bias && col0 + cc < g.N) bpre = *reinterpret_cast<const f32x4*>(x.bias + col0 + cc);
+    // four rows in flight per trip: fully unrolled (32 trips of the 256x256 kernel) the epilogue alone was 250 KB of code
+#pragma unroll 4
     for (int it = 0; it < 32 * NI / RPI; ++it) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(lds + (it * RPI + rr) * PITCH + cc);
-        epilogue_row4<false>(g, x, row0 + it * RPI + rr, col0 + cc, v);      // (only the 256x256 large-grid kernel comes through here)
+        epilogue_row4<false>(g, x, row0 + it * RPI + rr, col0 + cc, v, &bpre);      // (only the large-grid kernels come through here)
     }
 }
 

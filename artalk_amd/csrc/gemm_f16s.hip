@@ -900,7 +900,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
             }
     }
     EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
-    const bool can_defer = epi.vec && !g.R && !g.gate && nk >= 4;
+    const bool can_defer = epi.vec && !g.R && !g.gate && nk >= 5;      // four K steps before the last one carry the stores
     float* const C0 = g.C;
     const float* const bias0 = g.bias;
 
@@ -926,6 +926,10 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
         const unsigned hp = a_off[kb][0] + sb, lp = a_off[kb][1] + sb;
         if (i == 0) { ah[0] = lds_read128<0>(hp); al[0] = lds_read128<0>(lp); }
         else { ah[1] = lds_read128<4096>(hp); al[1] = lds_read128<4096>(lp); }
+    };
+    auto rotate_keep = [&]() {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { keep[0][0][e] = keep[0][1][e]; keep[0][1][e] = keep[1][0][e]; keep[1][0][e] = keep[1][1][e]; }
     };
     auto substep = [&](int kt_issue, int buf, unsigned sb, auto issue_tag, auto kb_tag, auto i_tag) {
         constexpr bool ISSUE = decltype(issue_tag)::value;
@@ -965,11 +969,11 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
         substep(kt_issue, buf, sb, issue_tag, I1{}, I0{});
         substep(kt_issue, buf, sb, issue_tag, I1{}, I1{});
         if (dq >= 0) {
-            const int row0 = pm0 + wm * 64 + r, col0 = pn0 + wn * 64;
-            if (dq == 0) epilogue_tile32_store<false>(g, pC, row0, col0, h, keep[0][0]);
-            else if (dq == 1) epilogue_tile32_store<false>(g, pC, row0, col0 + 32, h, keep[0][1]);
-            else if (dq == 2) epilogue_tile32_store<false>(g, pC, row0 + 32, col0, h, keep[1][0]);
-            else epilogue_tile32_store<false>(g, pC, row0 + 32, col0 + 32, h, keep[1][1]);
+            // ONE copy of the store code: the sub-tile to finish is always keep[0][0], the other three move up behind it (48 register
+            // moves per sub-tile; with a copy per sub-tile and per K-step variant the kernel was 197 KB of code, three times the
+            // instruction cache two CUs share, and a byte-identical second instantiation ran 27 % slower than the first)
+            epilogue_tile32_store<false>(g, pC, pm0 + wm * 64 + (dq >> 1) * 32 + r, pn0 + wn * 64 + (dq & 1) * 32, h, keep[0][0]);
+            rotate_keep();
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1050,10 +1054,11 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
             } else {                 // edge tile, residual or gate: finish it now (bias is already in)
                 EpiCtx e2 = epi;
                 e2.bias = nullptr;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) epilogue_tile32<true, false>(g, e2, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, keep[i][j]);
+#pragma nounroll
+                for (int dq = 0; dq < 4; ++dq) {      // one copy of the code here too (see kstep)
+                    epilogue_tile32<true, false>(g, e2, m0 + wm * 64 + (dq >> 1) * 32 + r, n0 + wn * 64 + (dq & 1) * 32, h, keep[0][0]);
+                    rotate_keep();
+                }
                 // a full fp32 tile issued exactly 16 store instructions behind the next tile's first stage (P8 results and
                 // partial tiles: wait for everything)
                 behind = (full && !g.c_p8) ? 16 : 0;
@@ -1063,11 +1068,11 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
         t = t_next; m0 = nm0; n0 = nn0;
     }
     if (pending) {
-        const int row0 = pm0 + wm * 64 + r, col0 = pn0 + wn * 64;
-        epilogue_tile32_store<false>(g, pC, row0, col0, h, keep[0][0]);
-        epilogue_tile32_store<false>(g, pC, row0, col0 + 32, h, keep[0][1]);
-        epilogue_tile32_store<false>(g, pC, row0 + 32, col0, h, keep[1][0]);
-        epilogue_tile32_store<false>(g, pC, row0 + 32, col0 + 32, h, keep[1][1]);
+#pragma nounroll
+        for (int dq = 0; dq < 4; ++dq) {
+            epilogue_tile32_store<false>(g, pC, pm0 + wm * 64 + (dq >> 1) * 32 + r, pn0 + wn * 64 + (dq & 1) * 32, h, keep[0][0]);
+            rotate_keep();
+        }
     }
 }
 
