@@ -271,6 +271,25 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
         }
     }
 }
+// All TM x TN sub-tiles of a wave through ONE copy of epilogue_tile32: the sub-tile to finish is always acc[0][0] and the others move
+// up behind it (16 register moves per remaining sub-tile and trip) - for kernels whose epilogue is cold or rare code.  Not for the
+// fp32 128x128 kernel and the non-persistent two-workgroup kernel: their exposed epilogues overlap the sub-tiles' loads and
+// stores when unrolled (looped: f32 mode 222 -> 238 ms per step).  scale: factor applied first (1 for none).
+template <bool P8OK, bool GUARD, int TM, int TN>
+__device__ __forceinline__ void epilogue_tiles(const GemmArgs& g, const EpiCtx& x, int row0, int col0, int h, f32x16 (&acc)[TM][TN],
+                                               float scale = 1.0f) {
+    f32x16* a = &acc[0][0];
+#pragma nounroll
+    for (int t = 0; t < TM * TN; ++t) {
+        if (scale != 1.0f) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a[0][e] *= scale;
+        }
+        epilogue_tile32<P8OK, GUARD>(g, x, row0 + (t / TN) * 32, col0 + (t % TN) * 32, h, a[0]);
+#pragma unroll
+        for (int u = 0; u + 1 < TM * TN; ++u) a[u] = a[u + 1];
+    }
+}
 // Store-only form of epilogue_tile32 for a tile whose bias is already added and that has no gate / residual, every lane valid and
 // the 16-byte path available (the deferred epilogue of gemm_p8_2wgp_kernel): activation, then exactly 4 store instructions.
 template <bool GUARD = true>

@@ -212,14 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
         return;
     }
     const EpiCtx epi = make_epi(g, g.bias ? g.bias + z * g.sBias : nullptr, g.C + z * g.sC, g.R ? g.R + z * g.sR : nullptr);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
-            epilogue_tile32(g, epi, m0 + wm * (BM / WM) + i * 32 + r, n0 + wn * (BN / WN) + j * 32, h, acc[i][j]);
-        }
+    epilogue_tiles<true, true, TM, TN>(g, epi, m0 + wm * (BM / WM) + r, n0 + wn * (BN / WN), h, acc, kOutScale);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -656,16 +649,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         epilogue_wave_lds<2, 2>(g, epi, lds, m0 + wm * 128 + 64, n0 + wn * 64, lane, hi2);
     } else {
-        auto epi_tile = [&](auto i_tag, auto j_tag) {
-            constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
-            epilogue_tile32<true, false>(g, epi, m0 + wm * 128 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);
-        };
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-        epi_tile(I0{}, I0{}); epi_tile(I0{}, I1{}); epi_tile(I1{}, I0{}); epi_tile(I1{}, I1{});
-        epi_tile(I2{}, I0{}); epi_tile(I2{}, I1{}); epi_tile(I3{}, I0{}); epi_tile(I3{}, I1{});
+        epilogue_tiles<true, false, 4, 2>(g, epi, m0 + wm * 128 + r, n0 + wn * 64, h, acc, kOutScale);
     }
     if constexpr (ABL == 6) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -849,7 +833,8 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
         if (P) partial_tile32(g, P, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);     // raw sums: splitk_reduce_kernel finishes
         else epilogue_tile32<true, false>(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);
     };
-    {
+    {   // four copies of the epilogue code on purpose: this kernel's epilogue is not hidden behind its own main loop, and the
+        // sub-tiles' loads and stores overlap when unrolled (the looped form of common.h cost the fp32 kernel 7 %)
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         epi_tile(I0{}, I0{}); epi_tile(I0{}, I1{}); epi_tile(I1{}, I0{}); epi_tile(I1{}, I1{});
     }
@@ -1055,7 +1040,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
                 EpiCtx e2 = epi;
                 e2.bias = nullptr;
 #pragma nounroll
-                for (int dq = 0; dq < 4; ++dq) {      // one copy of the code here too (see kstep)
+                for (int dq = 0; dq < 4; ++dq) {      // one copy of the code here too (see kstep; unrolled it measured 0.6 ms per step slower)
                     epilogue_tile32<true, false>(g, e2, m0 + wm * 64 + (dq >> 1) * 32 + r, n0 + wn * 64 + (dq & 1) * 32, h, keep[0][0]);
                     rotate_keep();
                 }
@@ -1258,11 +1243,7 @@ __global__ __launch_bounds__(256) void gemm_p8_sm_kernel(const GemmArgs g) {
         return;
     }
     const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            epilogue_tile32(g, epi, m0 + wm * (BM / 2) + i * 32 + r, n0 + wn * (BN / 2) + j * 32, h, acc[i][j]);
+    epilogue_tiles<true, true, TM, TN>(g, epi, m0 + wm * (BM / 2) + r, n0 + wn * (BN / 2), h, acc);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1552,13 +1533,14 @@ __global__ __launch_bounds__(512) void posconv_p8_kernel(const GemmArgs g, int T
     }
 
     const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+#pragma nounroll
+    for (int i = 0; i < 2; ++i) {                            // one copy of the epilogue code (common.h, epilogue_tiles)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] *= kOutScale;
+        for (int e = 0; e < 16; ++e) acc[0][e] *= kOutScale;
         const int t = wm * 64 + 32 * i + r;                  // frame inside the chunk; rows >= Ts belong to nobody
         const int row = t < Ts ? (int)(row0 + t) : g.M;
-        epilogue_tile32(g, epi, row, grp * CG + wn * 32, h, acc[i]);
+        epilogue_tile32(g, epi, row, grp * CG + wn * 32, h, acc[0]);
+        acc[0] = acc[1];
     }
 }
 // g: A = input hidden states (fp32, row stride lda, rows chunk * Ts + t), Wp = packed weights [1024][128 * 64] (ldw = 8192),
