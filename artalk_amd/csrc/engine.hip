@@ -112,6 +112,7 @@ struct artalk_model {
     std::map<std::string, int> audit_index;
     int posconv_lds = 1;              // tuning (ARTALK_POSCONV_LDS): LDS-resident positional convolution in f16x3 mode
     int hist_kv_batched = 1;          // tuning (ARTALK_HIST_KV_BATCHED): history K/V of all blocks as one GEMM over column groups
+    int sm_big_cfg = 0, sm_big_min = 400;      // tuning (ARTALK_SM_BIG_CFG / _MIN): small-grid kernel configuration for unsplit grids of >= min tiles
     int sm_split_768 = 1;             // tuning (ARTALK_SM_SPLIT768): split K = 768 GEMMs of the smallest scale steps too (deep-ring kernels)
     int stream_B = 0;                 // streams opened by artalk_stream_begin (history lives in the workspace)
     Workspace* view = nullptr;        // workspace view (clip sub-range) the body launchers currently work on; null = m->ws
@@ -441,6 +442,7 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
             while (S > 1 && (int64_t)S * g.M * g.N > cw.splitk_floats) { --S; cfg = -1; }
             if (S == 5 || S == 7) { --S; }        // the unrolled reduce kernels exist for 2, 3, 4, 6, 8 slabs
             if (S > 1) { g.splitk = S; g.partial = cw.splitk; if (g.force_cfg < 0) g.force_cfg = cfg; }
+            else if (m->sm_big_cfg > 0 && tiles >= m->sm_big_min && g.force_cfg < 0) g.force_cfg = m->sm_big_cfg;
         } else if (tiles < lim) {
             int S = std::min(std::min(g.K / 64, (tgt + tiles - 1) / tiles), 16);
             while (S > 1 && (int64_t)S * g.M * g.N > cw.splitk_floats) --S;
@@ -990,6 +992,8 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
     artalk_model* m = new artalk_model();
     m->cfg = c; m->device = device_id;
     if (const char* e = getenv("ARTALK_SM_SPLIT768")) m->sm_split_768 = atoi(e);
+    if (const char* e = getenv("ARTALK_SM_BIG_CFG")) m->sm_big_cfg = atoi(e);
+    if (const char* e = getenv("ARTALK_SM_BIG_MIN")) m->sm_big_min = atoi(e);
     if (const char* e = getenv("ARTALK_HIST_KV_BATCHED")) m->hist_kv_batched = atoi(e);
     if (const char* e = getenv("ARTALK_POSCONV_LDS")) m->posconv_lds = atoi(e);
     // conv stack geometry: T_l valid frames; row stride S_l per chunk with S_l = 2*S_{l+1} so that one GEMM covers all chunks

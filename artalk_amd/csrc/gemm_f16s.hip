@@ -1581,6 +1581,7 @@ void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s) {
         case 24: launch_p8_sm_cfg<64, 64, 5>(g, s); break;
         case 25: launch_p8_sm_cfg<64, 128, 5>(g, s); break;
         case 26: launch_p8_sm_cfg<128, 64, 5>(g, s); break;
+        case 27: launch_p8_sm_cfg<64, 64, 3>(g, s); break;
         default: launch_p8_sm_cfg<64, 64, 4>(g, s); break;
     }
 }
