@@ -112,6 +112,7 @@ struct artalk_model {
     std::map<std::string, int> audit_index;
     int posconv_lds = 1;              // tuning (ARTALK_POSCONV_LDS): LDS-resident positional convolution in f16x3 mode
     int hist_kv_batched = 1;          // tuning (ARTALK_HIST_KV_BATCHED): history K/V of all blocks as one GEMM over column groups
+    int skinny_max_m = 0;             // experiment (ARTALK_SKINNY_MAX_M, 0 = off): AR scale steps of up to this many rows take the skinny kernels (ar_skinny.hip; measured: no gain)
     int sm_big_cfg = 0, sm_big_min = 400;      // tuning (ARTALK_SM_BIG_CFG / _MIN): small-grid kernel configuration for unsplit grids of >= min tiles
     int sm_split_768 = 1;             // tuning (ARTALK_SM_SPLIT768): split K = 768 GEMMs of the smallest scale steps too (deep-ring kernels)
     int stream_B = 0;                 // streams opened by artalk_stream_begin (history lives in the workspace)
@@ -450,7 +451,7 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
         }
     }
     const bool dominant = !m->in_body && g.M > 0 &&
-                          (split ? (g.a_packed ? (gemm_p8_eligible(g) && gemm_p8_variant(g) == 0) : gemm_f16s_config(g) == 0) : gemm_config(g) == 4);
+                          (split ? (g.a_packed ? (gemm_p8_eligible(g) && gemm_p8_variant(g) == 1) : gemm_f16s_config(g) == 0) : gemm_config(g) == 4);
     size_t i0 = 0, i1 = 0;
     if (m->profiling && dominant) next_event(m, s, &i0);
     if (g.a_packed && !split) { m->err = "internal: P8 activation handed to an fp32 GEMM"; m->sticky_error = true; return false; }
@@ -725,7 +726,46 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
             return n;
         };
         bool have_ln = false;                                  // w.xmod already holds the norm the next GEMM reads
-        for (int l = 0; l < c.ar_depth; ++l) {
+        // experiment, off by default: four skinny launches per block on the smallest scale steps (LayerNorms fused into q|k|v and
+        // FFN-in, no split-K passes).  113 -> 65 launches per 1-token step, but a 16-column sliver engages only N / 16 CUs: 9-10 us
+        // per LayerNorm-fused launch, 15 us for FFN-out against 17 for the split GEMM + fused reduce/LayerNorm - 0.1 ms of a 35 ms
+        // body at 16 rows, slower at 80.  The headroom audit reads the LayerNorm outputs, so it keeps the tiled path.
+        const bool skinny = p8 && M <= m->skinny_max_m && !m->audit;
+        for (int l = 0; skinny && l < c.ar_depth; ++l) {
+            const ARLayer& L = m->ar[l];
+            const float* ada = w.ada + (long)l * 6 * kE;
+            float* cache = w.cache + l * cache_l;
+            const LnArgs n1 = ln_args(l, 0), n2 = ln_args(l, 1);
+            GemmArgs q;
+            q.W = L.qkv_w; q.Wp = packed_of(m, L.qkv_w); q.ldw = kE; q.bias = L.qkv_b; q.C = cache; q.ldc = 3 * kE;
+            q.cmap = rowmap(pn, 2 * kNTok, kNTok + off); q.M = M; q.N = 3 * kE; q.K = kE; q.status = w.status;
+            GemmArgs pj;
+            pj.A = w.attn_out; pj.lda = kE; pj.a_packed = 1; pj.W = L.proj_w; pj.Wp = packed_of(m, L.proj_w); pj.ldw = kE; pj.bias = L.proj_b;
+            pj.C = w.x; pj.ldc = kE; pj.gate = ada; pj.ldg = ldada; pj.gmap = amap; pj.R = w.x; pj.ldr = kE; pj.M = M; pj.N = kE; pj.K = kE;
+            pj.status = w.status;
+            GemmArgs f1;
+            f1.W = L.ffn1_w; f1.Wp = packed_of(m, L.ffn1_w); f1.ldw = kE; f1.bias = L.ffn1_b; f1.C = w.ffn_h; f1.ldc = 4 * kE; f1.c_p8 = 1;
+            f1.act = ACT_GELU_TANH; f1.M = M; f1.N = 4 * kE; f1.K = kE; f1.status = w.status;
+            GemmArgs f2;
+            f2.A = w.ffn_h; f2.lda = 4 * kE; f2.a_packed = 1; f2.W = L.ffn2_w; f2.Wp = packed_of(m, L.ffn2_w); f2.ldw = 4 * kE; f2.bias = L.ffn2_b;
+            f2.C = w.x; f2.ldc = kE; f2.gate = ada + kE; f2.ldg = ldada; f2.gmap = amap; f2.R = w.x; f2.ldr = kE; f2.M = M; f2.N = kE; f2.K = 4 * kE;
+            f2.status = w.status;
+            if (l == 0 && !(ar_skinny_eligible(q, &n1) && ar_skinny_eligible(pj, nullptr) && ar_skinny_eligible(f1, &n2) && ar_skinny_eligible(f2, nullptr))) {
+                m->err = "internal: skinny AR kernels not applicable"; m->sticky_error = true; return;
+            }
+            launch_ar_skinny(q, &n1, s);
+            AttnArgs a;
+            a.Q = cache + (long)(kNTok + off) * 3 * kE; a.K = cache + kE; a.V = cache + 2 * kE;
+            a.ldq = a.ldk = a.ldv = 3 * kE; a.q_bstride = a.k_bstride = a.v_bstride = (long)2 * kNTok * 3 * kE;
+            a.O = w.attn_out; a.ldo = kE; a.o_bstride = (long)pn * kE;
+            a.B = B; a.H = c.ar_heads; a.HD = kE / c.ar_heads; a.Lq = pn; a.Lk = kNTok + off + pn; a.scale = 1.0f;
+            a.l2norm = 1; a.qscale = L.qscale; a.out_p8 = p8; a.split16 = p8; a.status = w.status;
+            launch_attention(a, s);
+            launch_ar_skinny(pj, nullptr, s);
+            launch_ar_skinny(f1, &n2, s);
+            launch_ar_skinny(f2, nullptr, s);
+        }
+        for (int l = 0; !skinny && l < c.ar_depth; ++l) {
             const ARLayer& L = m->ar[l];
             const float* ada = w.ada + (long)l * 6 * kE;
             float* cache = w.cache + l * cache_l;
@@ -992,6 +1032,7 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
     artalk_model* m = new artalk_model();
     m->cfg = c; m->device = device_id;
     if (const char* e = getenv("ARTALK_SM_SPLIT768")) m->sm_split_768 = atoi(e);
+    if (const char* e = getenv("ARTALK_SKINNY_MAX_M")) m->skinny_max_m = atoi(e);
     if (const char* e = getenv("ARTALK_SM_BIG_CFG")) m->sm_big_cfg = atoi(e);
     if (const char* e = getenv("ARTALK_SM_BIG_MIN")) m->sm_big_min = atoi(e);
     if (const char* e = getenv("ARTALK_HIST_KV_BATCHED")) m->hist_kv_batched = atoi(e);
@@ -1577,7 +1618,8 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
     if (!A || !Wp || !C || K % 32 != 0 || M <= 0 || N <= 0 || (M <= 32 && (force_cfg & 0xff) < 20)) return ARTALK_EINVAL;
     GemmArgs g;
     g.A = (const float*)A; g.a_packed = a_packed; g.lda = lda; g.W = nullptr; g.Wp = (const unsigned int*)Wp; g.ldw = K; g.bias = bias;
-    g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act; g.force_cfg = force_cfg;
+    g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act & 0xff; g.force_cfg = force_cfg;
+    g.c_p8 = (act >> 8) & 1;      // tuning: bit 8 of `act` = result in the P8 split format (same pitch)
     if (force_cfg >= 2) {   // LDS-DMA pipelined kernel (needs both operands in P8); 3 / 5 select the pipeline depth, 6 = 256x128 tiles, 2 = default
         if (!a_packed) return ARTALK_EINVAL;
         g.force_cfg = force_cfg == 99 ? -1 : force_cfg;   // 99: the engine's own choice between the production kernels
@@ -1606,6 +1648,21 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
     } else {
         launch_gemm_f16s(g, (hipStream_t)stream);
     }
+    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+}
+
+int artalk_op_ar_skinny(const void* A_p8, const float* X, const float* scale, const float* shift, float eps, const void* Wp, const float* bias,
+                        const float* gate, const float* R, float* C, int M, int N, int K, int act, void* stream) {
+    if (!Wp || !C || (!A_p8 && !X) || M <= 0) return ARTALK_EINVAL;
+    GemmArgs g;
+    g.A = (const float*)A_p8; g.lda = K; g.a_packed = A_p8 ? 1 : 0; g.Wp = (const unsigned int*)Wp; g.ldw = K; g.bias = bias;
+    g.C = C; g.ldc = N; g.gate = gate; g.ldg = N; g.R = R; g.ldr = N; g.M = M; g.N = N; g.K = K;
+    g.act = act & 0xff; g.c_p8 = (act >> 8) & 1;      // act | 0x100: result in the P8 split format
+    LnArgs ln;
+    ln.X = X; ln.ldx = K; ln.scale = scale; ln.shift = shift; ln.ldm = K; ln.M = M; ln.D = K; ln.eps = eps;
+    const LnArgs* lp = X ? &ln : nullptr;
+    if (!ar_skinny_eligible(g, lp)) return ARTALK_EINVAL;
+    launch_ar_skinny(g, lp, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }
 

@@ -1646,12 +1646,14 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
             break;
     }
 }
-// 0: two-workgroup 128x128 kernel (default), 1: 256x256 kernel.  The big tile halves the operand bytes per flop but its 256 KiB
-// epilogue is not overlapped and its grid is four times coarser: it wins once the grid is >= 10 rounds deep (the conv stack and the
-// AdaLN table: 354 vs 329 and 330 vs 306 TF/s), loses on the encoder GEMMs (profiles/r01_gemm_f16s_bench.log).
+// 0: two-workgroup 128x128 kernel, 1: 256x256 kernel.  The big tile halves the operand bytes per flop (its main loop runs faster)
+// but its 256 KiB epilogue is not overlapped and its grid is four times coarser: it wins from ~3.5 rounds of 256 workgroups on
+// (wav2vec2 q|k|v and FFN-in GEMMs 360 / 384 vs 327 / 342 TF/s, conv1 390 vs 337, AdaLN table 373 vs 316:
+// profiles/r02_gemm_f16s_bench.log; in the model, where those results leave in P8 and through GELU, 1.0 ms per step) and loses on
+// the 300-tile out-projection / FFN-out GEMMs (266 / 305 vs 311 / 338).
 int gemm_p8_variant(const GemmArgs& g) {
     const long t256sq = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
-    static const long min256 = getenv("ARTALK_P8_256_MIN") ? atol(getenv("ARTALK_P8_256_MIN")) : 2560;      // tuning
+    static const long min256 = getenv("ARTALK_P8_256_MIN") ? atol(getenv("ARTALK_P8_256_MIN")) : 800;      // tuning
     return (t256sq >= min256 && g.N % 256 == 0 && g.ngrp == 0) ? 1 : 0;      // column groups: the 128x128 kernels only
 }
 bool gemm_p8_eligible(const GemmArgs& g) {

@@ -98,6 +98,10 @@ struct LnArgs {
     int junk_period = 0, junk_from = 0;
 };
 void launch_layernorm(const LnArgs& a, hipStream_t s);
+// Skinny split GEMM of the 1- / 5-token AR scale steps (ar_skinny.hip): one 16 x 16 result sliver per workgroup over the whole K,
+// optionally with the AdaLN-modulated LayerNorm `ln` of its input fused in front (then g.A is unused and ln->Y is not written).
+bool ar_skinny_eligible(const GemmArgs& g, const LnArgs* ln);
+void launch_ar_skinny(const GemmArgs& g, const LnArgs* ln, hipStream_t s);
 
 // softmax(scale * Q K^T [+mask]) V, fp32 MFMA, online softmax over 64-key blocks staged in LDS.
 struct AttnArgs {

@@ -39,8 +39,8 @@ MODES = {
     "f32": ("f32", "gemm_f32_kernel<128, 128, 2, 2, 16, 0, 0>",
             "gemm_f32_kernel<128,128,2,2,16,0,0> (v_mfma_f32_32x32x2_f32): every launch of it (wav2vec2 conv/encoder GEMMs, AdaLN table)",
             PEAK_F32_MFMA_TFLOPS, "fp32 MFMA peak"),
-    "f16x3": ("f32 (operands split into 2 fp16, 3 fp16 MFMA products per fp32 product, fp32 accumulate)", "gemm_p8_2wgp_kernel<0>",
-              "gemm_p8_2wgp_kernel<0> (128x128 tiles, two persistent workgroups per CU, LDS-DMA staged, deferred epilogue, v_mfma_f32_32x32x16_f16 x3 per k-block): every launch of it (the wav2vec2 encoder GEMMs)",
+    "f16x3": ("f32 (operands split into 2 fp16, 3 fp16 MFMA products per fp32 product, fp32 accumulate)", "gemm_p8_256_kernel<0>",
+              "gemm_p8_256_kernel<0> (256x256 tiles, 8 waves of 128x64, LDS-DMA staged, v_mfma_f32_32x32x16_f16 x3 per k-block, coalesced epilogue through wave-private LDS): every launch of it (wav2vec2 q|k|v and FFN-in GEMMs, conv1-3 as GEMMs, AdaLN table); the out-projection / FFN-out GEMMs run on gemm_p8_2wgp_kernel (profiles/)",
               PEAK_F16_MFMA_TFLOPS / 3.0, "dense fp16 MFMA peak 2500 TF/s / 3 MFMA products per algorithmic product"),
 }
 GOLDEN_SET = os.path.join(REPO, "tests", "golden", "full_cfg2_synth8.npz")    # reference outputs for seeds 0..7 (even seeds unstyled)

@@ -132,6 +132,61 @@ def test_gemm_p8_dma_pipeline_and_producers():
             assert err < 2e-6, (Ms, cfg, err)
 
 
+def _unpack_p8(t_i32, scale=16.0):
+    """P8 split format (common.h) -> float64: every 8 elements are 32 bytes [8 x f16 hi][8 x f16 lo], value = (hi + lo) / scale."""
+    M, K = t_i32.shape
+    h = t_i32.cpu().view(torch.float16).reshape(M, K // 8, 2, 8).double()
+    return ((h[:, :, 0, :] + h[:, :, 1, :]) / scale).reshape(M, K)
+
+
+@pytest.mark.parametrize("M,N,K,ln,act,gated,p8out", [
+    (16, 2304, 768, True, 0, False, False),       # q|k|v of the 1-token scale step: AdaLN-LayerNorm fused in front
+    (80, 768, 768, False, 0, True, False),        # attention projection of the 5-token step: gate + residual in place
+    (75, 3072, 768, True, 2, False, True),        # FFN-in: LayerNorm in front, gelu(tanh), P8 result, ragged M
+    (16, 768, 3072, False, 0, True, False),       # FFN-out: K = 3072 over 16 waves
+    (5, 768, 3072, False, 0, True, False),
+])
+def test_ar_skinny(M, N, K, ln, act, gated, p8out):
+    """Skinny split GEMM of the smallest AR scale steps (ar_skinny.hip) vs float64 (reference app/transformer.py:30-43)."""
+    capi, L = _lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    X = torch.randn(M, K, generator=g) * 1.5 + 0.2
+    dW, db = _dev(W), _dev(bias)
+    Wp = torch.empty(N, K, dtype=torch.int32, device="cuda")
+    assert L.artalk_op_pack_split(_p(dW), _p(Wp), N * K, 1, None) == 0
+    if ln:
+        sc, sh = torch.randn(M, K, generator=g) * 0.3, torch.randn(M, K, generator=g) * 0.3
+        A = F.layer_norm(X.double(), (K,), None, None, 1e-6) * (1 + sc.double()) + sh.double()
+        dX, dsc, dsh = _dev(X), _dev(sc), _dev(sh)
+        a_args = (None, _p(dX), _p(dsc), _p(dsh))
+    else:
+        A = X.double()
+        dX = _dev(X)
+        Ap = torch.empty(M, K, dtype=torch.int32, device="cuda")
+        assert L.artalk_op_pack_split(_p(dX), _p(Ap), M * K, 0, None) == 0
+        a_args = (_p(Ap), None, None, None)
+    ref = A @ W.double().t() + bias.double()
+    if act == 2:
+        ref = F.gelu(ref, approximate="tanh")
+    gate = res = None
+    if gated:
+        gate, res = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+        ref = res.double() + gate.double() * ref
+    dg = _dev(gate) if gated else None
+    out = _dev(res.clone()) if gated else torch.full((M, N), float("nan"), device="cuda")      # residual in place, as the model runs it
+    if p8out:
+        out = torch.zeros(M, N, dtype=torch.int32, device="cuda")
+    rc = L.artalk_op_ar_skinny(a_args[0], a_args[1], a_args[2], a_args[3], 1e-6, _p(Wp), _p(db), _p(dg), _p(out) if gated else None,
+                               _p(out), M, N, K, act | (0x100 if p8out else 0), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = _unpack_p8(out) if p8out else out.cpu().double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+
+
 def test_gemm_exact_integers():
     """A = I-like and asymmetric small integers: the MFMA lane maps (no row/col swap) are exact in fp32."""
     capi, L = _lib()

@@ -28,6 +28,7 @@ if only:
 # GEMM_ROTATE=n: cycle through n copies of the weight matrix, so that (as in the model, whose 12 blocks hold 340 MB of split
 # weights) a launch does not find its weights in L2 / Infinity Cache from the previous launch
 ROT = int(os.environ.get("GEMM_ROTATE", "1"))
+ACT = int(os.environ.get("GEMM_ACT", "0"), 0)      # activation | 0x100 = P8 result (timing only: the error column is then meaningless)
 if os.environ.get("GEMM_VARIANTS"):
     variants = [tuple(int(v) for v in x.split(":")) for x in os.environ["GEMM_VARIANTS"].split(",")]
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -44,7 +45,7 @@ for name, M, N, K in SHAPES:
         best = 1e9
         n = 3 if M * N * K > 1e11 else (10 if ROT == 1 else ROT)
         a = Ap if apk else A
-        L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wp), p(b), p(Cc), M, N, K, 0, cfg, s)      # warm-up (allocates the split-K scratch)
+        L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wp), p(b), p(Cc), M, N, K, ACT, cfg, s)      # warm-up (allocates the split-K scratch)
         torch.cuda.synchronize()
         graph = None
         if os.environ.get("GEMM_GRAPH", "1") == "1" and M * N * K < 1e11:
@@ -53,7 +54,7 @@ for name, M, N, K in SHAPES:
             with torch.cuda.graph(graph):
                 gs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
                 for it in range(n):
-                    L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wps[it % ROT]), p(b), p(Cc), M, N, K, 0, cfg, gs)
+                    L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wps[it % ROT]), p(b), p(Cc), M, N, K, ACT, cfg, gs)
         for rnd in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -61,7 +62,7 @@ for name, M, N, K in SHAPES:
                 graph.replay()
             else:
                 for it in range(n):
-                    L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wps[it % ROT]), p(b), p(Cc), M, N, K, 0, cfg, s)
+                    L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wps[it % ROT]), p(b), p(Cc), M, N, K, ACT, cfg, s)
             e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / n)
         err = float((Cc[:256].double() - ref).abs().max() / ref.abs().max())
