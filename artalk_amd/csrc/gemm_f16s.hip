@@ -632,7 +632,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
     if constexpr (ABL == 6) { if (tid == 0) stamps[2] = wall_clock64(); }
 
     const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
-    if (epi.vec) {      // coalesced: two passes (m tiles 0-1, then 2-3) through this wave's 17 KiB slice of LDS
+    if (epi.vec && ABL != 1) {      // coalesced: two passes (m tiles 0-1, then 2-3) through this wave's 17 KiB slice of LDS (ABL 1: tuning, direct stores)
         __builtin_amdgcn_s_barrier();      // every wave has consumed its last fragments
         constexpr int SLICE = 64 * 68;
         float* lds = reinterpret_cast<float*>(smem_p8) + wave * SLICE;
@@ -1616,6 +1616,7 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
         case 16: hipLaunchKernelGGL((gemm_p8_kernel<128, 4, 6>), dim3(t128), dim3(512), 4 * 256 * 128, s, g); break;
         case 7: hipLaunchKernelGGL((gemm_p8_256_kernel<0>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
         case 17: hipLaunchKernelGGL((gemm_p8_256_kernel<6>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
+        case 10: hipLaunchKernelGGL((gemm_p8_256_kernel<1>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;   // tuning: direct-store epilogue
         case 18: hipLaunchKernelGGL((gemm_p8_2wg_kernel<6>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;
         case 9: hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, g); break;   // persistent, deferred epilogue
         case 19: hipLaunchKernelGGL((gemm_p8_2wg_kernel<7>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;   // ablation: no epilogue

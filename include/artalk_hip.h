@@ -137,8 +137,8 @@ int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, v
  * LAST artalk_infer's numbers (milliseconds / counters):
  *   out[0] style  out[1] wav2vec2 conv stack  out[2] wav2vec2 encoder  out[3] AdaLN table GEMM
  *   out[4] AR scale steps (level 1: whole captured body)  out[5] VAE decode+re-encode (level 2 only; + initial history)
- *   out[6] total  out[7] bracketed launches of the dominant kernel (f16x3 mode: gemm_p8_2wgp_kernel, the 128x128-tile LDS-DMA split GEMM of
- *   the wav2vec2 encoder; f32 mode: the 128x128-tile fp32 MFMA GEMM)  out[8] their summed ms
+ *   out[6] total  out[7] bracketed launches of the dominant kernel (f16x3 mode: gemm_p8_256_kernel, the 256x256-tile LDS-DMA split GEMM of
+ *   the wav2vec2 q|k|v / FFN-in layers, conv1-3 and the AdaLN table; f32 mode: the 128x128-tile fp32 MFMA GEMM)  out[8] their summed ms
  *   out[9] their summed FLOP */
 int artalk_set_profiling(artalk_model* m, int level);
 int artalk_get_profile(artalk_model* m, double* out, int n);
