@@ -592,6 +592,195 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
     }
 }
 
+// ---- One workgroup per (clip, head) for sequences of up to 208 queries x 256 keys with P8 operands (the wav2vec2 encoder: 199 x 199,
+// the VAE stacks): attention_f16_kernel stages every 64-key block of K and V once per 64-query workgroup - four workgroups per head
+// each pay four exposed global -> LDS round trips, and a launch is those latencies, not its 3 us of matrix work per workgroup.  Here
+// ALL keys of the head are staged once (K and V, hi and lo images: 4 x 224 rows x 160 B = 140 KB, every load of the workgroup in
+// flight before the first wait), one barrier, then up to 13 waves of 16 queries run attention_f16_kernel's block loop out of LDS with
+// no further synchronisation.  Same blocks, same order, same arithmetic per query: results are bit-identical to that kernel's.
+// wav2vec2 layer 120 -> 111 us, VAE decoder 15.4 -> 14.1 us (the launch is now one staging latency + ~10 us of matrix / softmax work
+// per head with one workgroup per CU; start staggers between the waves of a SIMD changed nothing), 0.7 ms per step in the model.
+constexpr int kWideMaxWaves = 13, kWideMaxKeys = 256;
+template <int FASTEXP>
+__global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(const AttnArgs a) {
+    constexpr int HD = 64, KB = 64, PB = 160, NT = kWideMaxWaves * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wide_smem[];
+    const int lkp = (a.Lk + 31) & ~31;             // rows staged: the P V step walks pairs of 16-key tiles
+    unsigned char* const Kh = wide_smem;
+    unsigned char* const Kl = Kh + lkp * PB;
+    unsigned char* const Vh = Kl + lkp * PB;
+    unsigned char* const Vl = Vh + lkp * PB;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = wave * 16;
+    const int qi = q0 + r;
+    const bool qvalid = qi < a.Lq;
+    const bool wave_active = q0 < a.Lq;
+
+    const float* Kb = a.K + (long)b * a.k_bstride + h * HD;
+    const float* Vb = a.V + (long)b * a.v_bstride + h * HD;
+    // ---- stage: one 8-element group (16 B hi + 16 B lo) of K and of V per thread and pass, all passes' loads issued first ----
+    constexpr int NPASS = (kWideMaxKeys * 8 + NT - 1) / NT;      // 3
+    {
+        h8_t kh[NPASS], kl[NPASS], vh[NPASS], vl[NPASS];
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int idx = tid + i * NT;
+            const int row = idx >> 3, g8 = idx & 7;
+            const h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            kh[i] = z; kl[i] = z; vh[i] = z; vl[i] = z;
+            if (row < a.Lk) {
+                const unsigned char* kp = reinterpret_cast<const unsigned char*>(Kb + (long)row * a.ldk) + g8 * 32;
+                const unsigned char* vp = reinterpret_cast<const unsigned char*>(Vb + (long)row * a.ldv) + g8 * 32;
+                kh[i] = *reinterpret_cast<const h8_t*>(kp); kl[i] = *reinterpret_cast<const h8_t*>(kp + 16);
+                vh[i] = *reinterpret_cast<const h8_t*>(vp); vl[i] = *reinterpret_cast<const h8_t*>(vp + 16);
+            }
+        }
+        // Q fragments (B operand of S^T): lane (r, g) holds Q[qi][8g + 32kb .. +7], hi | lo as stored
+        h8_t qh_[2], ql_[2];
+        {
+            const unsigned char* qp = reinterpret_cast<const unsigned char*>(a.Q + (long)b * a.q_bstride + (long)min(qi, a.Lq - 1) * a.ldq + h * HD);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                qh_[kb] = *reinterpret_cast<const h8_t*>(qp + (g + 4 * kb) * 32);
+                ql_[kb] = *reinterpret_cast<const h8_t*>(qp + (g + 4 * kb) * 32 + 16);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int idx = tid + i * NT;
+            const int row = idx >> 3, g8 = idx & 7;
+            if (row < lkp) {
+                *reinterpret_cast<h8_t*>(Kh + row * PB + g8 * 16) = kh[i];
+                *reinterpret_cast<h8_t*>(Kl + row * PB + g8 * 16) = kl[i];
+                *reinterpret_cast<h8_t*>(Vh + row * PB + g8 * 16) = vh[i];
+                *reinterpret_cast<h8_t*>(Vl + row * PB + g8 * 16) = vl[i];
+            }
+        }
+        __syncthreads();
+        if (!wave_active) return;
+        const h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+        const h8_t qh[2] = {qvalid ? qh_[0] : z, qvalid ? qh_[1] : z}, ql[2] = {qvalid ? ql_[0] : z, qvalid ? ql_[1] : z};
+        const float sfix = a.scale / (kActScale * kActScale);      // scores of P8 operands carry 16 * 16 and no softmax scale yet
+        const int klim = (a.split_q > 0 && qi < a.split_q) ? a.split_k : a.Lk;
+        // attention_f16_kernel decides per 64-query workgroup how far the key loop runs; the same bound here keeps the block sequence
+        // (and with it every rounding) of a query identical to that kernel's
+        const int qblk_last = min((q0 & ~63) + 63, a.Lq - 1);
+        const int lk_wg = (a.split_q > 0 && qblk_last < a.split_q) ? a.split_k : a.Lk;
+
+        float m_run = -INFINITY, l_part = 0.f;
+        f32x4 ot[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { f32x4 zz = {0.f, 0.f, 0.f, 0.f}; ot[d] = zz; }
+        const int trq = r >> 2, trp = r & 3;
+
+        for (int kb0 = 0; kb0 < lk_wg; kb0 += KB) {
+            const int ntile = min(4, (a.Lk - kb0 + 15) >> 4);
+            f32x4 st[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (t < ntile) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const int off = (kb0 + t * 16 + r) * PB + (8 * g + 32 * kb) * 2;
+                        const h8_t kh2 = *reinterpret_cast<const h8_t*>(Kh + off), kl2 = *reinterpret_cast<const h8_t*>(Kl + off);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh2, qh[kb], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl2, qh[kb], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh2, ql[kb], acc, 0, 0, 0);
+                    }
+                }
+                st[t] = acc;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kidx = kb0 + t * 16 + 4 * g + j;
+                    const float sv = (kidx < klim) ? st[t][j] * sfix : -INFINITY;
+                    st[t][j] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = FASTEXP ? __expf(m_run - m_safe) : expf(m_run - m_safe);
+            m_run = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p = FASTEXP ? __expf(st[t][j] - m_safe) : expf(st[t][j] - m_safe);
+                    st[t][j] = p;
+                    ps += p;
+                }
+            l_part = l_part * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) ot[d] *= alpha;
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                if (2 * T < ntile) {
+                    f16x4_t h0, l0, h1, l1;
+                    split4(st[2 * T], h0, l0);
+                    split4(st[2 * T + 1], h1, l1);
+                    const h8_t ph = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    const h8_t pl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                    const int row1 = kb0 + T * 32 + 4 * g + trq, row2 = row1 + 16;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const int col = (16 * dt + 4 * trp) * 2;
+                        const f16x4_t a1 = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_raw*)(Vh + row1 * PB + col)));
+                        const f16x4_t a2 = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_raw*)(Vh + row2 * PB + col)));
+                        const f16x4_t b1 = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_raw*)(Vl + row1 * PB + col)));
+                        const f16x4_t b2 = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_raw*)(Vl + row2 * PB + col)));
+                        const h8_t vh2 = {a1[0], a1[1], a1[2], a1[3], a2[0], a2[1], a2[2], a2[3]};
+                        const h8_t vl2 = {b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3]};
+                        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh2, ph, ot[dt], 0, 0, 0);
+                        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl2, ph, ot[dt], 0, 0, 0);
+                        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh2, pl, ot[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        float l = l_part;
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (qvalid) {
+            const float inv = 1.0f / (l * kActScale);      // P8 values carry x16
+            float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int d0 = 16 * dt + 4 * g;
+                const float o0 = ot[dt][0] * inv, o1 = ot[dt][1] * inv, o2 = ot[dt][2] * inv, o3 = ot[dt][3] * inv;
+                if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status);
+                else { const f32x4 o = {o0, o1, o2, o3}; *reinterpret_cast<f32x4*>(op + d0) = o; }
+            }
+        }
+    }
+}
+
+void attention_prepare() {      // more than the default 64 KB of dynamic LDS for the wide kernel; called at model creation (outside any capture)
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  4 * kWideMaxKeys * 160);
+        attr_set = true;
+    }
+}
+static long wide_min_heads() {      // tuning: fewest (clip, head) pairs for which one workgroup per pair is taken
+    static const long v = getenv("ARTALK_ATTN_WIDE_MIN") ? atol(getenv("ARTALK_ATTN_WIDE_MIN")) : 1;
+    return v;
+}
 void launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.Lq <= 0) return;
     static const int short_lq = getenv("ARTALK_ATTN_SHORT_LQ") ? atoi(getenv("ARTALK_ATTN_SHORT_LQ")) : 64;   // tuning
@@ -602,7 +791,13 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
     dim3 grid((a.Lq + 63) / 64, a.H, a.B), block(256);
     // v_exp_f32-based exp (1.2e-6 relative at |x| = 20, where p = 2e-9) by default: 154 -> 137 us per wav2vec2 layer; the fp32 kernels keep expf
     static const int fastexp = getenv("ARTALK_ATTN_FASTEXP") ? atoi(getenv("ARTALK_ATTN_FASTEXP")) : 1;
-    if (a.HD == 64 && a.split16 && a.qkv_p8 && !a.l2norm)
+    static const int wide = getenv("ARTALK_ATTN_WIDE") ? atoi(getenv("ARTALK_ATTN_WIDE")) : 1;      // tuning: 0 = 64-query workgroups everywhere
+    if (a.HD == 64 && a.split16 && a.qkv_p8 && !a.l2norm && wide && a.Lq <= kWideMaxWaves * 16 && a.Lk <= kWideMaxKeys &&
+        (long)a.B * a.H >= wide_min_heads()) {
+        const size_t lds = (size_t)4 * ((a.Lk + 31) & ~31) * 160;
+        attention_prepare();
+        hipLaunchKernelGGL((attention_f16_wide_kernel<1>), dim3(1, a.H, a.B), dim3(kWideMaxWaves * 64), lds, s, a);
+    } else if (a.HD == 64 && a.split16 && a.qkv_p8 && !a.l2norm)
         hipLaunchKernelGGL((attention_f16_kernel<1, 1>), grid, block, 0, s, a);
     else if (a.HD == 64 && a.split16 && fastexp)
         hipLaunchKernelGGL(attention_f16_kernel<1>, grid, block, 0, s, a);

@@ -1051,6 +1051,7 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
     }
     for (int i = 0; i < 5; ++i) { m->pn[i] = c.patch_nums[i]; m->off[i + 1] = m->off[i] + c.patch_nums[i]; }
     if (init_ms_tables() != 0) { g_create_error = "uploading the interpolation tables to the device failed"; delete m; return ARTALK_EHIP; }
+    attention_prepare();
     const int rc = build_registry(m);
     if (rc != ARTALK_OK) { g_create_error = m->err; artalk_destroy(m); return rc; }
     *out = m;

@@ -119,6 +119,7 @@ struct AttnArgs {
     int* status = nullptr;                           // out_p8: range guard (see GemmArgs::status)
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
+void attention_prepare();      // one-time kernel attributes (call once per process before the first captured launch)
 
 // ---- wav2vec2 front-end ----
 // per-chunk mean / unbiased std, writes (x-mean)/(std+1e-6); chunk c is read at audio + src_off[c]
