@@ -19,7 +19,7 @@ DTYPE_F32, DTYPE_I64 = 0, 1
 # every symbol include/artalk_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "artalk_create", "artalk_destroy", "artalk_last_error", "artalk_set_tensor", "artalk_finalize_weights",
-    "artalk_reserve", "artalk_workspace_bytes", "artalk_weight_bytes", "artalk_infer", "artalk_get_status", "artalk_poll_status", "artalk_style_encode", "artalk_stream_begin", "artalk_stream_chunk", "artalk_stream_end", "artalk_savgol", "artalk_flame_create", "artalk_flame_verts", "artalk_flame_destroy", "artalk_flame_last_error",
+    "artalk_reserve", "artalk_workspace_bytes", "artalk_weight_bytes", "artalk_infer", "artalk_get_status", "artalk_poll_status", "artalk_last_ticket", "artalk_get_status_of", "artalk_style_encode", "artalk_stream_begin", "artalk_stream_chunk", "artalk_stream_end", "artalk_savgol", "artalk_flame_create", "artalk_flame_verts", "artalk_flame_destroy", "artalk_flame_last_error",
     "artalk_set_profiling", "artalk_get_profile", "artalk_set_graphs", "artalk_set_overlap", "artalk_set_audit", "artalk_get_audit", "artalk_set_precision",
     "artalk_op_gemm", "artalk_op_gemm_ex", "artalk_op_gemm_f16s", "artalk_op_pack_split", "artalk_op_gemm_f16s_packed", "artalk_op_mfma_f32_peak", "artalk_op_layernorm", "artalk_op_ar_skinny", "artalk_op_attention", "artalk_op_w2v_front", "artalk_op_resample_mean", "artalk_op_pool_silu",
     "artalk_op_bsq_history",
@@ -104,6 +104,10 @@ def lib() -> C.CDLL:
     L.artalk_get_status.restype = i32
     L.artalk_poll_status.argtypes = [vp, C.POINTER(C.c_int)]
     L.artalk_poll_status.restype = i32
+    L.artalk_last_ticket.argtypes = [vp]
+    L.artalk_last_ticket.restype = C.c_longlong
+    L.artalk_get_status_of.argtypes = [vp, C.c_longlong, C.POINTER(C.c_int)]
+    L.artalk_get_status_of.restype = i32
     L.artalk_style_encode.argtypes = [vp, vp, i32, vp, vp]
     L.artalk_style_encode.restype = i32
     L.artalk_stream_begin.argtypes = [vp, i32, vp, vp, vp]

@@ -166,7 +166,11 @@ struct artalk_model {
     struct Stage { long* src = nullptr; uint8_t* has = nullptr; hipEvent_t done = nullptr; bool used = false; };
     Stage stage[kStageSlots];
     int stage_cap_c = 0, stage_cap_b = 0, stage_next = 0;
-    int* h_status = nullptr; hipEvent_t status_ev = nullptr; bool status_pending = false;
+    // one slot per call in flight (ring of kStatusSlots, indexed by the call's ticket): a caller that keeps several calls queued reads
+    // each call's own word (artalk_get_status_of)
+    static constexpr int kStatusSlots = 4;
+    int* h_status = nullptr; hipEvent_t status_ev[kStatusSlots] = {nullptr, nullptr, nullptr, nullptr}; bool status_pending = false;
+    long long ticket = 0;          // number of calls that have published a status word; the last one's ticket is `ticket`, slot (ticket - 1) % kStatusSlots
 };
 
 namespace {
@@ -925,9 +929,9 @@ void free_stage(artalk_model* m) {
 }
 int ensure_stage(artalk_model* m, int maxB, int maxC) {
     if (!m->h_status) {
-        HIPCHK(m, hipHostMalloc(reinterpret_cast<void**>(&m->h_status), 4 * sizeof(int), hipHostMallocDefault));
-        std::memset(m->h_status, 0, 4 * sizeof(int));
-        HIPCHK(m, hipEventCreateWithFlags(&m->status_ev, hipEventDisableTiming));
+        HIPCHK(m, hipHostMalloc(reinterpret_cast<void**>(&m->h_status), artalk_model::kStatusSlots * sizeof(int), hipHostMallocDefault));
+        std::memset(m->h_status, 0, artalk_model::kStatusSlots * sizeof(int));
+        for (auto& e : m->status_ev) HIPCHK(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     if (maxB <= m->stage_cap_b && maxC <= m->stage_cap_c) return ARTALK_OK;
     for (auto& st : m->stage) if (st.used) HIPCHK(m, hipEventSynchronize(st.done));
@@ -950,8 +954,12 @@ int next_stage(artalk_model* m, artalk_model::Stage** out) {
 }
 // end of a call: hand the device status word to the host asynchronously (artalk_get_status / artalk_poll_status read it)
 int publish_status(artalk_model* m, hipStream_t s) {
-    HIPCHK(m, hipMemcpyAsync(m->h_status, m->ws.status, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(m, hipEventRecord(m->status_ev, s));
+    const int slot = (int)(m->ticket % artalk_model::kStatusSlots);
+    // the slot's previous user is kStatusSlots calls back: its copy has long landed unless the caller queued more calls than slots
+    if (m->ticket >= artalk_model::kStatusSlots) HIPCHK(m, hipEventSynchronize(m->status_ev[slot]));
+    HIPCHK(m, hipMemcpyAsync(m->h_status + slot, m->ws.status, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(m, hipEventRecord(m->status_ev[slot], s));
+    ++m->ticket;
     m->status_pending = true;
     return ARTALK_OK;
 }
@@ -1076,7 +1084,7 @@ void artalk_destroy(artalk_model* m) {
     free_stage(m);
     for (auto& st : m->stage) if (st.done) (void)hipEventDestroy(st.done);
     if (m->h_status) (void)hipHostFree(m->h_status);
-    if (m->status_ev) (void)hipEventDestroy(m->status_ev);
+    for (auto& e : m->status_ev) if (e) (void)hipEventDestroy(e);
     for (void* p : m->allocs) if (p) (void)hipFree(p);
     for (void* p : m->ws_allocs) if (p) (void)hipFree(p);
     delete m;
@@ -1515,18 +1523,31 @@ int artalk_get_status(artalk_model* m, int* flags, void* stream) {
     if (!m || !flags) return ARTALK_EINVAL;
     if (!m->status_pending) { *flags = 0; return ARTALK_OK; }
     (void)hipSetDevice(m->device);
-    HIPCHK(m, hipEventSynchronize(m->status_ev));
-    *flags = m->h_status[0];
+    const int slot = (int)((m->ticket - 1) % artalk_model::kStatusSlots);
+    HIPCHK(m, hipEventSynchronize(m->status_ev[slot]));
+    *flags = m->h_status[slot];
+    return ARTALK_OK;
+}
+long long artalk_last_ticket(artalk_model* m) { return m ? m->ticket : -1; }
+int artalk_get_status_of(artalk_model* m, long long ticket, int* flags) {
+    if (!m || !flags || ticket <= 0 || ticket > m->ticket) return ARTALK_EINVAL;
+    if (ticket + artalk_model::kStatusSlots <= m->ticket) { m->err = "artalk_get_status_of: that call's status slot has been reused"; return ARTALK_EINVAL; }
+    if (!m->status_pending) { *flags = 0; return ARTALK_OK; }      // the workspace was re-created since: nothing of that call is left
+    (void)hipSetDevice(m->device);
+    const int slot = (int)((ticket - 1) % artalk_model::kStatusSlots);
+    HIPCHK(m, hipEventSynchronize(m->status_ev[slot]));
+    *flags = m->h_status[slot];
     return ARTALK_OK;
 }
 int artalk_poll_status(artalk_model* m, int* flags) {
     if (!m || !flags) return ARTALK_EINVAL;
     if (!m->status_pending) { *flags = 0; return ARTALK_OK; }
     (void)hipSetDevice(m->device);
-    const hipError_t e = hipEventQuery(m->status_ev);
+    const int slot = (int)((m->ticket - 1) % artalk_model::kStatusSlots);
+    const hipError_t e = hipEventQuery(m->status_ev[slot]);
     if (e == hipErrorNotReady) return ARTALK_EBUSY;
     if (e != hipSuccess) { m->err = std::string("hipEventQuery: ") + hipGetErrorString(e); return ARTALK_EHIP; }
-    *flags = m->h_status[0];
+    *flags = m->h_status[slot];
     return ARTALK_OK;
 }
 

@@ -12,6 +12,7 @@ PyTorch is used for device memory and streams only; all arithmetic runs in ``lib
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import List, Optional, Sequence
 
@@ -68,6 +69,7 @@ class BitwiseARModel:
         self._style_cache = {}      # key -> (style tensor kept alive, (768,) condition on the device)
         self._overlap = False       # overlapped wav2vec2 / AR schedule (set_overlap), opt-in
         self._stream = None      # dedicated HIP stream (hipGraph capture is not allowed on the legacy default stream)
+        self._h2d_stream = None  # uploads of host clips (inference_batch)
         self.last_aux = {}
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -110,7 +112,7 @@ class BitwiseARModel:
         L = capi.lib()
         if self._h is not None and self._loaded:      # reloading: derived layouts/packed copies belong to the old weights
             L.artalk_destroy(self._h)
-            self._h, self._loaded, self._stream = None, False, None
+            self._h, self._loaded, self._stream, self._h2d_stream = None, False, None, None
         self._style_cache = {}
         if self._h is None:
             h = C.c_void_p()
@@ -168,6 +170,18 @@ class BitwiseARModel:
         return int(f.value)
 
     _status = status
+
+    def last_ticket(self) -> int:
+        """Ticket of the call that was enqueued last (see ``status_of``)."""
+        return int(capi.lib().artalk_last_ticket(self._h))
+
+    def status_of(self, ticket: int) -> int:
+        """Waits for the call with that ticket and returns ITS health flags (artalk_get_status_of): what a loop that keeps the next
+        batch enqueued while it looks at the previous one uses instead of ``status()``."""
+        f = C.c_int(0)
+        if capi.lib().artalk_get_status_of(self._h, C.c_longlong(ticket), C.byref(f)) != capi.OK:
+            raise RuntimeError("artalk status query failed: " + self._err())
+        return int(f.value)
 
     def _trip_to_f32(self, what: str):
         """An activation left fp16's range in f16x3 mode: switch to exact-f32 GEMMs for good (a checkpoint that trips once will
@@ -376,8 +390,13 @@ class BitwiseARModel:
 
     @torch.no_grad()
     def inference_batch(self, audios: Sequence[torch.Tensor], style_motions: Optional[Sequence[Optional[torch.Tensor]]] = None,
-                        return_aux: bool = False) -> List[torch.Tensor]:
+                        return_aux: bool = False, check: bool = True) -> List[torch.Tensor]:
         """B independent clips -> list of ``(ceil(N_b/640), 106)`` float32 tensors on ``self.device``.
+
+        ``check=False`` returns without waiting for the call's health flags (the one host synchronisation of a call), so that a
+        serving loop can enqueue the next batch - whose upload then runs under this batch's kernels - before it looks at this one:
+        the caller takes ``last_ticket()`` right after the call and asks ``status_of(ticket)`` before it uses the results (non-zero
+        in f16x3 mode: redo that batch with ``set_precision("f32")``).
 
         With ``return_aux`` the per-chunk bits, history bits and wav2vec2 features of the call are kept in
         ``self.last_aux`` (used by the parity tests).
@@ -406,15 +425,25 @@ class BitwiseARModel:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=dev)
             caller = torch.cuda.current_stream()
-            if packed and n_samples[0] == maxch * spc:
-                audio_pad = audios.to(device=dev, dtype=torch.float32, non_blocking=True)      # already whole chunks
-            else:
-                audio_pad = torch.zeros(B, maxch * spc, dtype=torch.float32, device=dev)   # zero padding of app/models.py:81-85
-                if packed:
-                    audio_pad[:, :n_samples[0]] = audios.to(device=dev, dtype=torch.float32, non_blocking=True)
+            # Host clips are staged on a stream of their own: nothing orders their H2D copies behind the previous call's kernels, so in a
+            # serving loop the upload of batch i+1 runs under the compute of batch i.  Device inputs keep the caller's stream order.
+            on_host = all(not a.is_cuda for a in audios) if not packed else not audios.is_cuda
+            if os.environ.get("ARTALK_H2D_STREAM", "1") == "0":      # tuning: uploads in the caller's stream order
+                on_host = False
+            if self._h2d_stream is None:
+                self._h2d_stream = torch.cuda.Stream(device=dev)
+            stage = self._h2d_stream if on_host else caller
+            with torch.cuda.stream(stage):
+                if packed and n_samples[0] == maxch * spc:
+                    audio_pad = audios.to(device=dev, dtype=torch.float32, non_blocking=True)      # already whole chunks
                 else:
-                    for pos, i in enumerate(order):      # host clips (pinned or not) go straight into their row: one H2D copy each
-                        audio_pad[pos, :n_samples[i]].copy_(audios[i], non_blocking=True)
+                    audio_pad = torch.zeros(B, maxch * spc, dtype=torch.float32, device=dev)   # zero padding of app/models.py:81-85
+                    if packed:
+                        audio_pad[:, :n_samples[0]] = audios.to(device=dev, dtype=torch.float32, non_blocking=True)
+                    else:
+                        for pos, i in enumerate(order):      # host clips (pinned or not) go straight into their row: one H2D copy each
+                            audio_pad[pos, :n_samples[i]].copy_(audios[i], non_blocking=True)
+            self._stream.wait_stream(stage)
             self._stream.wait_stream(caller)
             style_t, has = self._style_rows(style_motions, order, B)
             out = torch.zeros(B, maxch * 100, self.cfg.motion_dim, dtype=torch.float32, device=dev)   # zeros: rows past a clip's last chunk
@@ -434,7 +463,7 @@ class BitwiseARModel:
                     t.record_stream(self._stream)
             if rc != capi.OK:
                 raise RuntimeError("artalk_infer failed ({}): {}".format(rc, self._err()))
-            if self._precision == "f16x3" and self.check_finite and self.status() != 0:
+            if check and self._precision == "f16x3" and self.check_finite and self.status() != 0:
                 # an activation left fp16's range: redo this call with exact fp32 MFMA GEMMs (never silently return NaNs) and
                 # stay in f32 mode - a checkpoint that trips once trips again, and both runs per call would cost 3.4x
                 self._trip_to_f32("inference_batch")

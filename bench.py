@@ -97,6 +97,7 @@ def parse_args(argv=None):
     ap.add_argument("--branches", type=int, default=0, help="concurrent clip groups of the AR body (0 = auto)")
     ap.add_argument("--splitk", default="0,0", help="tuning: split-K tile threshold,target workgroups (0 = keep)")
     ap.add_argument("--overlap", action="store_true", help="overlapped schedule: wav2vec2 of chunk index j+1 beside the AR/VAE body of j")
+    ap.add_argument("--synchronous", action="store_true", help="wait for every batch before the next one is enqueued (default: two batches in flight)")
     ap.add_argument("--resident", action="store_true", help="audio already in HBM, codes left in HBM (no PCIe copies in the step)")
     ap.add_argument("--force-collective", action="store_true", help="N = 1: still create the RCCL process group and run the all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,27 +195,59 @@ def main():
     mine = adist.shard_range(len(clips), rank, world)
     host_audio = [clips[i] for i in mine]                                         # pinned host memory
     dev_audio = [a.to(dev) for a in host_audio]                                   # the same clips resident in HBM (--resident)
-    host_out = torch.empty(B, frames_per_clip, cfg.motion_dim).pin_memory()       # D2H target of the local codes
-    state = {"resident": args.resident}
+    host_outs = [torch.empty(B, frames_per_clip, cfg.motion_dim).pin_memory() for _ in range(2)]   # D2H targets of the local codes (one per batch in flight)
+    state = {"resident": args.resident, "pipelined": not args.synchronous, "k": 0, "last_host": 0}
 
     def infer_fn(audios, styles):
         src = dev_audio if state["resident"] else audios                         # host tensors: H2D happens inside inference_batch
-        return model.inference_batch(src, styles)
+        return model.inference_batch(src, styles, check=not state["pipelined"])
+
+    # One step = upload of the 32 clips -> the path -> download of the codes.  As a serving loop would, the default loop keeps TWO
+    # batches in flight: batch i+1 is enqueued (its upload runs on its own stream under the kernels of batch i) before the host waits for
+    # batch i's health flags and download; --synchronous waits for every batch before it enqueues the next (reported as `synchronous`).
+    def submit():
+        outs = adist.run_sharded(infer_fn, clips, None, gather=collective, max_frames=frames_per_clip, force_collective=args.force_collective)
+        ticket = model.last_ticket()
+        local = outs[mine.start:mine.stop] if collective else outs
+        ev = None
+        if not state["resident"]:
+            slot = state["k"] % 2
+            host_outs[slot].copy_(torch.stack(list(local)), non_blocking=True)   # D2H of this rank's codes
+            ev = torch.cuda.Event()
+            ev.record()
+            state["last_host"] = slot
+        state["k"] += 1
+        return ticket, local, ev
+
+    def finish(p):
+        ticket, _, ev = p
+        if state["pipelined"] and model.status_of(ticket) != 0:
+            raise RuntimeError("range guard tripped during the benchmark: the f16x3 results of that batch are invalid")
+        if ev is not None:
+            ev.synchronize()
 
     def step():
-        outs = adist.run_sharded(infer_fn, clips, None, gather=collective, max_frames=frames_per_clip, force_collective=args.force_collective)
-        local = outs[mine.start:mine.stop] if collective else outs
-        if not state["resident"]:
-            host_out.copy_(torch.stack(list(local)), non_blocking=True)         # D2H of this rank's codes
-        return local
+        p = submit()
+        finish(p)
+        return p[1]
 
     def timed(n):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        prev, outs = None, None
         for _ in range(n):
-            outs = step()
+            cur = submit()
+            outs = cur[1]
+            if prev is not None:
+                finish(prev)
+            if not state["pipelined"]:
+                finish(cur)
+                cur = None
+            prev = cur
+        if prev is not None:
+            finish(prev)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -244,7 +277,7 @@ def main():
         if args.config == "full" and args.seconds == 10.0 and os.path.exists(GOLDEN_SET):
             g = np.load(GOLDEN_SET)
             f0, errs = 0, {}
-            res = host_out.numpy() if not state["resident"] else torch.stack(list(outs)).cpu().numpy()
+            res = host_outs[state["last_host"]].numpy() if not state["resident"] else torch.stack(list(outs)).cpu().numpy()
             for i in range(len(g["n_frames"])):
                 nf = int(g["n_frames"][i])
                 if int(g["style_seed"][i]) < 0 and int(g["seed"][i]) < B:         # the bench runs unstyled clips
@@ -285,6 +318,8 @@ def main():
                                    "hipGraph decode loop, deterministic synthetic weights (489.5 M params)",
                        "clips_per_gpu": B, "frames_per_clip": frames_per_clip, "precision": args.precision,
                        "model_config": args.config, "io": io,
+                       "loop": ("one batch at a time (host waits for each batch before enqueuing the next)" if args.synchronous else
+                                "two batches in flight: batch i+1 is enqueued, and uploads on its own stream, before the host waits for batch i"),
                        "collective": ("RCCL all_gather_into_tensor of the codes (backend nccl), world size %d" % world) if collective else None},
             "fps_per_clip": round(value / (B * world), 1),
             "algorithmic_tflops": round(value * GFLOP_PER_FRAME / 1e3, 2),
@@ -298,6 +333,14 @@ def main():
         }
 
     extras = world == 1 and not args.no_alt_mode
+    if extras and not args.synchronous:
+        # the same steps, one batch at a time: the host waits for every batch's health flags and download before it enqueues the next
+        state["pipelined"] = False
+        step(); torch.cuda.synchronize()
+        n = max(2, args.steps // 2)
+        dts, _ = timed(n)
+        state["pipelined"] = True
+        result["synchronous"] = {"value": round(n * B * frames_per_clip / dts, 1), "ms_per_step": round(dts / n * 1e3, 2)}
     if extras and not args.resident:
         # the same steps with the audio resident and the codes left in HBM (what round 1 reported): the PCIe share of the step
         state["resident"] = True

@@ -127,6 +127,11 @@ const char* artalk_flame_last_error(const artalk_flame* f);
  * means an activation left fp16's range: redo the call in f32 mode (the Python host does, and stays in f32). */
 int artalk_get_status(artalk_model* m, int* flags, void* stream);
 int artalk_poll_status(artalk_model* m, int* flags);
+/* Several calls in flight (a serving loop that enqueues batch i+1 before it looks at batch i): every call that publishes a status
+ * word gets a ticket (1, 2, ...; artalk_last_ticket right after the call returns it), and artalk_get_status_of waits for THAT call
+ * and returns its flags.  The words of the last 4 calls are kept: ARTALK_EINVAL for an older ticket. */
+long long artalk_last_ticket(artalk_model* m);
+int artalk_get_status_of(artalk_model* m, long long ticket, int* flags);
 
 /* Savitzky-Golay smoothing of inference.py:89-95 on the device: in/out [T][106] f32, T >= 9. */
 int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, void* stream);

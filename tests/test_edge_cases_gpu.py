@@ -94,6 +94,33 @@ def test_large_ragged_batch():
         _compare(outs[i].cpu().numpy(), bits[i], audios[i])
 
 
+def test_batches_in_flight_and_per_call_status():
+    """A serving loop that enqueues batch i+1 before it looks at batch i (``check=False`` + ``status_of(ticket)``): six different
+    batches queued back to back from pinned host memory give exactly what one-at-a-time calls give, every call has its own health
+    word (tickets count up by one per call), and a ticket older than the four kept slots is refused (include/artalk_hip.h)."""
+    from artalk_amd.synth import synth_audio
+    m = get_gpu_model("tiny")
+    m.set_precision("f16x3")
+    batches = [[torch.from_numpy(synth_audio(300 + 10 * k + i, 4.0 + i)).pin_memory() for i in range(3)] for k in range(6)]
+    want = [[o.cpu().clone() for o in m.inference_batch(b)] for b in batches]
+    t0 = m.last_ticket()
+    queued, tickets = [], []
+    for b in batches:
+        queued.append(m.inference_batch(b, check=False))
+        tickets.append(m.last_ticket())
+    assert tickets == list(range(t0 + 1, t0 + 7))
+    for tk in tickets[-4:]:
+        assert m.status_of(tk) == 0
+    with pytest.raises(RuntimeError):
+        m.status_of(tickets[0])            # its slot has been reused by a later call
+    torch.cuda.synchronize()
+    for got, ref in zip(queued, want):
+        for g, r in zip(got, ref):
+            assert torch.equal(g.cpu(), r)
+    assert m.status() == 0
+    m.set_precision("f32")
+
+
 def test_strict_state_dict_errors():
     """load_state_dict(strict=True) semantics of reference inference.py:28 through the C ABI."""
     from artalk_amd.model import BitwiseARModel
