@@ -293,9 +293,15 @@ __device__ __forceinline__ void epilogue_tiles(const GemmArgs& g, const EpiCtx& 
 // Store-only form of epilogue_tile32 for a tile whose bias is already added and that has no gate / residual, every lane valid and
 // the 16-byte path available (the deferred epilogue of gemm_p8_2wgp_kernel): activation, then exactly 4 store instructions.
 template <bool GUARD = true>
-__device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* C, int row, int col0, int h, f32x16& v) {
+__device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* C, int row, int col0, int h, f32x16& v, const f32x4* res = nullptr) {
     const long crow = map_row(g.cmap, row);
     apply_act16(v, g.act);
+    if (res) {      // residual of the deferred tile (4 runs of 4 columns, staged through LDS by the persistent kernel)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] += res[q][e];
+    }
     if (g.c_p8) {
         if (GUARD) p8_guard16(g.status, v);
 #pragma unroll

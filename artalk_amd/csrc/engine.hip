@@ -1060,6 +1060,7 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
     for (int i = 0; i < 5; ++i) { m->pn[i] = c.patch_nums[i]; m->off[i + 1] = m->off[i] + c.patch_nums[i]; }
     if (init_ms_tables() != 0) { g_create_error = "uploading the interpolation tables to the device failed"; delete m; return ARTALK_EHIP; }
     attention_prepare();
+    gemm_p8_prepare();
     const int rc = build_registry(m);
     if (rc != ARTALK_OK) { g_create_error = m->err; artalk_destroy(m); return rc; }
     *out = m;
@@ -1642,6 +1643,7 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
     g.A = (const float*)A; g.a_packed = a_packed; g.lda = lda; g.W = nullptr; g.Wp = (const unsigned int*)Wp; g.ldw = K; g.bias = bias;
     g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act & 0xff; g.force_cfg = force_cfg;
     g.c_p8 = (act >> 8) & 1;      // tuning: bit 8 of `act` = result in the P8 split format (same pitch)
+    if ((act >> 9) & 1) { g.R = C; g.ldr = N; }      // tuning: bit 9 = residual read from C (in place, as the encoder's out-projection / FFN-out run)
     if (force_cfg >= 2) {   // LDS-DMA pipelined kernel (needs both operands in P8); 3 / 5 select the pipeline depth, 6 = 256x128 tiles, 2 = default
         if (!a_packed) return ARTALK_EINVAL;
         g.force_cfg = force_cfg == 99 ? -1 : force_cfg;   // 99: the engine's own choice between the production kernels

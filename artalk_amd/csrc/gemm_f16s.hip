@@ -886,6 +886,13 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
     }
     EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
     const bool can_defer = epi.vec && !g.R && !g.gate && nk >= 5;      // four K steps before the last one carry the stores
+    // Residual tiles (out-projection, FFN-out) are deferred too when the launcher added 16 KiB of LDS (g.res_lds): the kept sub-tile's
+    // residual values come in by LDS-DMA at the top of its K step (4 x 1 KiB per wave, lane-private slots: each lane later reads back
+    // exactly the 16 bytes it asked for), so they cost no registers while the step's MFMAs run; immediate, such a tile cost the
+    // out-projection 15 us and FFN-out 20 us per launch
+    const bool defer_res = g.res_lds && epi.vec && g.R && !g.gate && !g.c_p8 && nk >= 5;
+    unsigned char* const res_lds = smem_p8 + 2 * STAGE_BYTES + wave * 4096;
+    bool pending_res = false;
     float* const C0 = g.C;
     const float* const bias0 = g.bias;
 
@@ -946,6 +953,15 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
         if (behind == 4) wait_vmcnt<4>(); else if (behind == 16) wait_vmcnt<16>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (dq >= 0 && pending_res) {      // (wave-uniform) residual of the sub-tile this step finishes: 4 DMA pieces, ahead of the stage's 8
+            const long crow = map_row(g.cmap, pm0 + wm * 64 + (dq >> 1) * 32 + r);
+            const float* rp = g.R + crow * g.ldr + pn0 + wn * 64 + (dq & 1) * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rp + 8 * q),
+                                                 (__attribute__((address_space(3))) void*)(res_lds + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         read_b(sb, 0);
         read_a(sb, 0, 0);
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -957,7 +973,16 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
             // ONE copy of the store code: the sub-tile to finish is always keep[0][0], the other three move up behind it (48 register
             // moves per sub-tile; with a copy per sub-tile and per K-step variant the kernel was 197 KB of code, three times the
             // instruction cache two CUs share, and a byte-identical second instantiation ran 27 % slower than the first)
-            epilogue_tile32_store<false>(g, pC, pm0 + wm * 64 + (dq >> 1) * 32 + r, pn0 + wn * 64 + (dq & 1) * 32, h, keep[0][0]);
+            if (pending_res) {
+                wait_vmcnt<8>();       // everything older than this step's 8 stage pieces: the 4 residual pieces have landed
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 rv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(res_lds + q * 1024 + lane * 16);
+                epilogue_tile32_store<false>(g, pC, pm0 + wm * 64 + (dq >> 1) * 32 + r, pn0 + wn * 64 + (dq & 1) * 32, h, keep[0][0], rv);
+            } else {
+                epilogue_tile32_store<false>(g, pC, pm0 + wm * 64 + (dq >> 1) * 32 + r, pn0 + wn * 64 + (dq & 1) * 32, h, keep[0][0]);
+            }
             rotate_keep();
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1034,9 +1059,9 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) keep[i][j][4 * q + e] = acc[i][j][4 * q + e] * kOutScale + b[e];
                 }
-            if (can_defer && full) {
-                pending = true; pm0 = m0; pn0 = n0; pC = epi.C;
-            } else {                 // edge tile, residual or gate: finish it now (bias is already in)
+            if ((can_defer || defer_res) && full) {
+                pending = true; pending_res = defer_res; pm0 = m0; pn0 = n0; pC = epi.C;
+            } else {                 // edge tile, gate, P8 result with a residual: finish it now (bias is already in)
                 EpiCtx e2 = epi;
                 e2.bias = nullptr;
 #pragma nounroll
@@ -1053,9 +1078,13 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
         t = t_next; m0 = nm0; n0 = nn0;
     }
     if (pending) {
+        EpiCtx e2 = epi;
+        e2.bias = nullptr; e2.C = pC;
 #pragma nounroll
         for (int dq = 0; dq < 4; ++dq) {
-            epilogue_tile32_store<false>(g, pC, pm0 + wm * 64 + (dq >> 1) * 32 + r, pn0 + wn * 64 + (dq & 1) * 32, h, keep[0][0]);
+            const int row = pm0 + wm * 64 + (dq >> 1) * 32 + r, col = pn0 + wn * 64 + (dq & 1) * 32;
+            if (pending_res) epilogue_tile32<true, false>(g, e2, row, col, h, keep[0][0]);      // last tile of this workgroup: plain residual loads
+            else epilogue_tile32_store<false>(g, pC, row, col, h, keep[0][0]);
             rotate_keep();
         }
     }
@@ -1595,6 +1624,13 @@ static bool epi_vec_host(const GemmArgs& g) {
     if (g.gate) bits |= (unsigned long long)g.ldg | ((unsigned long long)g.gate >> 2);
     return (bits & 3) == 0;
 }
+void gemm_p8_prepare() {      // more than the default 64 KB of dynamic LDS for the persistent kernel's residual slots (outside any capture)
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_2wgp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128 + 16384);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_2wgp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128 + 16384);
+    done = true;
+}
 void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
     if (g0.M <= 0 || g0.N <= 0) return;
     // No range guard in the epilogues of the large-grid kernels (compiled out: epilogue_tile32<.., GUARD = false>; with it the dominant
@@ -1618,7 +1654,14 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
         case 17: hipLaunchKernelGGL((gemm_p8_256_kernel<6>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
         case 10: hipLaunchKernelGGL((gemm_p8_256_kernel<1>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;   // tuning: direct-store epilogue
         case 18: hipLaunchKernelGGL((gemm_p8_2wg_kernel<6>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;
-        case 9: hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, g); break;   // persistent, deferred epilogue
+        case 9: {      // persistent, deferred epilogue
+            static const int res_defer9 = getenv("ARTALK_P8_RES_DEFER") ? atoi(getenv("ARTALK_P8_RES_DEFER")) : 1;
+            GemmArgs a = g;
+            a.res_lds = (res_defer9 && g.R && !g.gate && !g.c_p8 && epi_vec_host(g)) ? 1 : 0;
+            if (a.res_lds) gemm_p8_prepare();
+            hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128 + (a.res_lds ? 16384 : 0), s, a);
+            break;
+        }
         case 19: hipLaunchKernelGGL((gemm_p8_2wg_kernel<7>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;   // ablation: no epilogue
         default:
             if (cfg == 8 && g.force_cfg < 0 && g.splitk == 1 && persist && epi_vec_host(g) && (!g.graph_tag || t128 >= 1024)) {
@@ -1633,8 +1676,13 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
                 static const int tail_max = getenv("ARTALK_P8_TAIL") ? atoi(getenv("ARTALK_P8_TAIL")) : 0;
                 const bool tail = t128 > 512 && rem > 0 && rem <= tail_max && g.ngrp == 0;
                 if (tail) a.tile_end = t128 - rem;
-                if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wgp_kernel<1>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, a);
-                else hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128, s, a);
+                // residual tiles deferred too (tuning: ARTALK_P8_RES_DEFER=0 finishes them at once): 16 KiB more LDS, still two workgroups per CU
+                static const int res_defer = getenv("ARTALK_P8_RES_DEFER") ? atoi(getenv("ARTALK_P8_RES_DEFER")) : 1;
+                a.res_lds = (res_defer && g.R && !g.gate && !g.c_p8) ? 1 : 0;
+                if (a.res_lds) gemm_p8_prepare();
+                const size_t lds = 2 * 256 * 128 + (a.res_lds ? 16384 : 0);
+                if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wgp_kernel<1>), dim3(t128 < 512 ? t128 : 512), dim3(256), lds, s, a);
+                else hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), lds, s, a);
                 if (tail) {
                     GemmArgs b = g;
                     b.tail_t0 = t128 - rem;

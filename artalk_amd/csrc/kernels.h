@@ -54,6 +54,7 @@ struct GemmArgs {
     // small-grid kernel, so the last, partly filled round costs a quarter-tile's time instead of a whole tile's.  0 = unused.
     int tile_end = 0, tail_t0 = 0;
     int tile_gm = 0;     // tuning: row tiles per XCD tile group of the persistent kernel (0 = 4)
+    int res_lds = 0;     // persistent kernel: 16 KiB of LDS behind the two stages are there for the deferred residual tiles (launch_gemm_p8)
     int force_cfg = -1;  // >= 0: tile configuration override (tuning/tests)
     int graph_tag = 0;   // 1 for launches inside the captured AR/VAE body (separate kernel symbol, same code)
     int* status = nullptr;   // model status word: bit 3 is raised when a value leaves the range of the P8 format (c_p8 results, fp32 A split while staging)
@@ -72,6 +73,7 @@ int gemm_f16s_config(const GemmArgs& g);     // register-staged kernel: 0: 128x1
 void launch_gemm_f16s(const GemmArgs& g, hipStream_t s);
 bool gemm_p8_eligible(const GemmArgs& g);      // both operands in P8 and a large grid: the LDS-DMA kernels (gemm_p8_2wgp / _256)
 void launch_gemm_p8(const GemmArgs& g, hipStream_t s);
+void gemm_p8_prepare();      // one-time kernel attributes (call once per process before the first captured launch)
 int gemm_p8_variant(const GemmArgs& g);
 bool gemm_p8_sm_eligible(const GemmArgs& g);   // both operands in P8, any grid (split-K capable): small-tile LDS-DMA kernel
 void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s);        // 0: gemm_p8_2wg_kernel (128x128, two workgroups per CU), 1: gemm_p8_256_kernel
