@@ -164,7 +164,8 @@ __device__ __forceinline__ EpiCtx make_epi(const GemmArgs& g, const float* bias,
 // P8OK = false (the exact-fp32 kernels, which never produce a P8 result) compiles the split / guard paths out: with them in, the
 // 128x128 fp32 kernel went from 116 to 216 registers + scratch and the f32 mode from 227 to 665 ms per step.
 // GUARD = false (the large-grid kernels): no range guard in this epilogue (gemm_f16s.hip, launch_gemm_p8).
-template <bool P8OK = true, bool GUARD = true>
+// DUAL = true (the small-grid kernel): a fp32 result may be written a second time in the P8 format (g.c2, same pitch and row map).
+template <bool P8OK = true, bool GUARD = true, bool DUAL = false>
 __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx& x, int row, int col0, int h, f32x16& v) {   // v is clobbered
     const bool rok = row < g.M;
     const long crow = rok ? map_row(g.cmap, row) : 0;
@@ -204,7 +205,19 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
                     v[4 * q + e] = t + act_rv[q][e];
                 }
         }
-        if (P8OK && g.c_p8) {   // N % 8 == 0.  Pairs of 8-column groups (k, k+1): lanes h=0 end up with all of group k, lanes h=1 with group k+1
+        const bool dual = DUAL && g.c2 && !g.c_p8;
+        if (dual && rok) {      // the fp32 copy first; the P8 copy below takes the same values
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = col0 + 8 * q + 4 * h;
+                if (c < g.N) {
+                    const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(x.C + crow * g.ldc + c) = o;
+                }
+            }
+        }
+        float* const p8dst = dual ? g.c2 : x.C;
+        if (P8OK && (g.c_p8 || dual)) {   // N % 8 == 0.  Pairs of 8-column groups (k, k+1): lanes h=0 end up with all of group k, lanes h=1 with group k+1
             if (GUARD && rok) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -232,7 +245,7 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
                 }
                 const int gc = col0 + 16 * qp + 8 * h;
                 if (rok && gc < g.N) {
-                    unsigned char* o = reinterpret_cast<unsigned char*>(x.C + crow * g.ldc + gc);
+                    unsigned char* o = reinterpret_cast<unsigned char*>(p8dst + crow * g.ldc + gc);
                     const u32x4_t hi = {w[0][0], w[0][1], w[1][0], w[1][1]}, lo = {w[0][2], w[0][3], w[1][2], w[1][3]};
                     *reinterpret_cast<u32x4_t*>(o) = hi;
                     *reinterpret_cast<u32x4_t*>(o + 16) = lo;
@@ -275,7 +288,7 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
 // up behind it (16 register moves per remaining sub-tile and trip) - for kernels whose epilogue is cold or rare code.  Not for the
 // fp32 128x128 kernel and the non-persistent two-workgroup kernel: their exposed epilogues overlap the sub-tiles' loads and
 // stores when unrolled (looped: f32 mode 222 -> 238 ms per step).  scale: factor applied first (1 for none).
-template <bool P8OK, bool GUARD, int TM, int TN>
+template <bool P8OK, bool GUARD, int TM, int TN, bool DUAL = false>
 __device__ __forceinline__ void epilogue_tiles(const GemmArgs& g, const EpiCtx& x, int row0, int col0, int h, f32x16 (&acc)[TM][TN],
                                                float scale = 1.0f) {
     f32x16* a = &acc[0][0];
@@ -285,7 +298,7 @@ __device__ __forceinline__ void epilogue_tiles(const GemmArgs& g, const EpiCtx& 
 #pragma unroll
             for (int e = 0; e < 16; ++e) a[0][e] *= scale;
         }
-        epilogue_tile32<P8OK, GUARD>(g, x, row0 + (t / TN) * 32, col0 + (t % TN) * 32, h, a[0]);
+        epilogue_tile32<P8OK, GUARD, DUAL>(g, x, row0 + (t / TN) * 32, col0 + (t % TN) * 32, h, a[0]);
 #pragma unroll
         for (int u = 0; u + 1 < TM * TN; ++u) a[u] = a[u + 1];
     }

@@ -460,6 +460,13 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
     if (m->profiling && dominant) next_event(m, s, &i0);
     if (g.a_packed && !split) { m->err = "internal: P8 activation handed to an fp32 GEMM"; m->sticky_error = true; return false; }
     const bool dma = split && g.splitk == 1 && gemm_p8_eligible(g);
+    // second copy of the result in P8 (GemmArgs::c2): written by the small-grid kernel's epilogue when that kernel finishes the tiles
+    // itself, otherwise by a split pass over the fp32 result
+    float* const c2 = g.c2;
+    const bool c2_fused = c2 && !dma && split && gemm_p8_sm_eligible(g) && g.splitk == 1 && !g.c_p8 && (g.N % 8) == 0 && (g.ldc % 8) == 0 &&
+                          !g.gate && (g.ldr % 4) == 0 &&      // (the epilogue's 16-byte path: every pointer and row start aligned)
+                          (((unsigned long long)g.C | (unsigned long long)c2 | (unsigned long long)g.bias | (unsigned long long)g.R) & 15) == 0;
+    if (!c2_fused) g.c2 = nullptr;
     if (dma) launch_gemm_p8(g, s);
     else if (split && gemm_p8_sm_eligible(g)) launch_gemm_p8_sm(g, s);     // P8 activation, small grid (AR/VAE scale steps)
     else if (split) launch_gemm_f16s(g, s);
@@ -469,6 +476,7 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
         if (fuse_ln && splitk_reduce_ln_eligible(g, *fuse_ln)) { launch_splitk_reduce_ln(g, *fuse_ln, s); fused = true; }
         else launch_splitk_reduce(g, s);
     }
+    if (c2 && !c2_fused) launch_pack_split(g.C, reinterpret_cast<unsigned int*>(c2), (long)g.M * g.N, false, s, g.status);
     if (m->profiling && dominant) {
         next_event(m, s, &i1);
         m->dom_events.emplace_back(i0, gemm_flops(g));
@@ -479,8 +487,9 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
 enum { LF_EXACT = 1, LF_A_P8 = 2, LF_C_P8 = 4 };   // linear() flags: decision-critical (fp32 path) / A is in P8 / write C in P8
 // plain y = act(x W^T + b) [+ R]
 void linear(artalk_model* m, const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N, int K,
-            int act, const float* R, hipStream_t s, int flags = 0) {
+            int act, const float* R, hipStream_t s, int flags = 0, float* c2 = nullptr) {
     GemmArgs g;
+    g.c2 = c2;
     g.exact = flags & LF_EXACT; g.a_packed = (flags & LF_A_P8) ? 1 : 0; g.c_p8 = (flags & LF_C_P8) ? 1 : 0;
     g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act;
     g.R = R; g.ldr = ldc;
@@ -644,11 +653,10 @@ void run_vae_stack(artalk_model* m, const VAESide& S, int B, int T, int split, h
         a.split_q = split; a.split_k = split; a.out_p8 = p8; a.split16 = p8; a.status = p8 ? w.status : nullptr;
         launch_attention(a, s);
         audit(m, an + ".attn_out", w.vatt, M, H, H, p8, s);
-        linear(m, w.vatt, H, L.out_w, L.out_b, w.vh, H, M, H, H, ACT_NONE, w.vh, s, AP);
-        // the MLP reads the residual stream itself (no LayerNorm in front of it, bitwise_vae.py:139-145).  In f16x3 mode one split pass
-        // writes it in P8 so that the GEMM can stage it by LDS-DMA (the register-staged kernel on fp32 rows took 36 us at
-        // M = 6400, the pass + the small-grid kernel 4 + 15)
-        if (p8) launch_pack_split(w.vh, reinterpret_cast<unsigned int*>(w.vln), (long)M * H, false, s, w.status);
+        // the MLP reads the residual stream itself (no LayerNorm in front of it, bitwise_vae.py:139-145).  In f16x3 mode the
+        // out-projection writes it a second time in P8 (w.vln) so that the MLP GEMM can stage it by LDS-DMA (the register-staged
+        // kernel on fp32 rows took 36 us at M = 6400, a split pass + the small-grid kernel 4 + 15, the second copy from the epilogue 15)
+        linear(m, w.vatt, H, L.out_w, L.out_b, w.vh, H, M, H, H, ACT_NONE, w.vh, s, AP, p8 ? w.vln : nullptr);
         audit(m, an + ".residual", p8 ? w.vln : w.vh, M, H, H, p8, s);
         linear(m, p8 ? w.vln : w.vh, H, L.m1_w, L.m1_b, w.vmlp, F, M, F, H, ACT_GELU_TANH, nullptr, s, p8 ? (LF_A_P8 | LF_C_P8) : 0);
         audit(m, an + ".mlp_hidden", w.vmlp, M, F, F, p8, s);

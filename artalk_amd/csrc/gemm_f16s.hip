@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(256) void gemm_p8_sm_kernel(const GemmArgs g) {
         return;
     }
     const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
-    epilogue_tiles<true, true, TM, TN>(g, epi, m0 + wm * (BM / 2) + r, n0 + wn * (BN / 2), h, acc);
+    epilogue_tiles<true, true, TM, TN, true>(g, epi, m0 + wm * (BM / 2) + r, n0 + wn * (BN / 2), h, acc);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

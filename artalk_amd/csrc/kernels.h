@@ -33,6 +33,7 @@ struct GemmArgs {
     int exact = 0;                       // 1: decision-critical GEMM (logit / code heads), always on the fp32 MFMA path
     const float* bias = nullptr;
     float* C = nullptr; long ldc = 0; RowMap cmap = {INT_MAX, 0, 0};
+    float* c2 = nullptr;                 // optional: the (fp32) result once more in the P8 split format, same pitch (engine gemm(): the small-grid kernel writes both, otherwise a split pass follows; needs ldc == N and an identity cmap)
     const float* gate = nullptr; long ldg = 0; RowMap gmap = {INT_MAX, 0, 0};
     const float* R = nullptr; long ldr = 0;     // residual, addressed with cmap; may alias C
     int M = 0, N = 0, K = 0;
