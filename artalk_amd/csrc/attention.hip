@@ -770,12 +770,13 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
 }
 
 void attention_prepare() {      // more than the default 64 KB of dynamic LDS for the wide kernel; called at model creation (outside any capture)
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  4 * kWideMaxKeys * 160);
-        attr_set = true;
-    }
+    static bool done[64] = {};      // per device: the attribute belongs to the function on the current device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || done[dev]) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              4 * kWideMaxKeys * 160);
+    done[dev] = true;
 }
 static long wide_min_heads() {      // tuning: fewest (clip, head) pairs for which one workgroup per pair is taken
     static const long v = getenv("ARTALK_ATTN_WIDE_MIN") ? atol(getenv("ARTALK_ATTN_WIDE_MIN")) : 1;

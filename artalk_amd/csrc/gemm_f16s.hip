@@ -1577,10 +1577,13 @@ __global__ __launch_bounds__(512) void posconv_p8_kernel(const GemmArgs g, int T
 void launch_posconv_p8(const GemmArgs& g, int n_chunks, int T, int Ts, hipStream_t s) {
     if (n_chunks <= 0) return;
     const size_t lds = PC_WIN_BYTES + PC_STAGES * PC_STAGE;
-    static bool attr_set = false;
-    if (!attr_set) {      // more than the default 64 KB of dynamic LDS
+    static bool attr_set[64] = {};      // per device: more than the default 64 KB of dynamic LDS (this launch is never captured)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&posconv_p8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&posconv_p8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[dev] = true;
     }
     static const int mfma16 = getenv("ARTALK_POSCONV_MFMA16") ? atoi(getenv("ARTALK_POSCONV_MFMA16")) : 0;      // experiment, see the kernel
     if (mfma16) hipLaunchKernelGGL((posconv_p8_kernel<1>), dim3(n_chunks * 16), dim3(512), lds, s, g, T, Ts);
@@ -1625,11 +1628,13 @@ static bool epi_vec_host(const GemmArgs& g) {
     return (bits & 3) == 0;
 }
 void gemm_p8_prepare() {      // more than the default 64 KB of dynamic LDS for the persistent kernel's residual slots (outside any capture)
-    static bool done = false;
-    if (done) return;
+    static bool done[64] = {};      // per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || done[dev]) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_2wgp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128 + 16384);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_2wgp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128 + 16384);
-    done = true;
+    done[dev] = true;
 }
 void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
     if (g0.M <= 0 || g0.N <= 0) return;
