@@ -285,6 +285,45 @@ def test_attention(B, H, HD, Lq, Lk, l2norm, split):
             assert errp < 2e-5, errp
 
 
+_WIDE_CHILD = r"""
+import ctypes as C, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from artalk_amd import capi
+L = capi.lib()
+p = lambda t: C.c_void_p(t.data_ptr())
+B, H, HD, Lq, Lk, split = [int(x) for x in sys.argv[3:9]]
+g = torch.Generator().manual_seed(77)
+D = H * HD
+pk = []
+for n in (Lq, Lk, Lk):
+    t = torch.randn(B, n, D, generator=g).cuda()
+    o = torch.empty_like(t, dtype=torch.int32)
+    assert L.artalk_op_pack_split(p(t), p(o), t.numel(), 0, None) == 0
+    pk.append(o)
+out = torch.full((B, Lq, D), float("nan"), device="cuda")
+assert L.artalk_op_attention(p(pk[0]), p(pk[1]), p(pk[2]), p(out), B, H, HD, Lq, Lk, 0.125, 2 | 4, None, split, None) == 0
+torch.cuda.synchronize()
+np.save(sys.argv[2], out.cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,split", [(3, 16, 199, 199, 0), (2, 8, 200, 200, 100), (2, 8, 100, 100, 0)])
+def test_attention_wide_kernel_is_bit_identical(tmp_path, B, H, Lq, Lk, split):
+    """attention_f16_wide_kernel (one workgroup per (clip, head), all keys staged once) must give bit for bit what the 64-query
+    kernel gives: the switch is read once per process, so each arm runs in a child process (ARTALK_ATTN_WIDE=1 / 0)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for wide in ("1", "0"):
+        f = str(tmp_path / f"wide{wide}.npy")
+        env = dict(os.environ, ARTALK_ATTN_WIDE=wide)
+        subprocess.run([sys.executable, "-c", _WIDE_CHILD, root, f, str(B), str(H), "64", str(Lq), str(Lk), str(split)], check=True, env=env,
+                       timeout=300)
+        outs.append(np.load(f))
+    assert np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_w2v_front():
     """audio normalisation + conv0 + LN + GELU vs torch (reference ops: wav2vec.py:22-27, hf:291-299)."""
     capi, L = _lib()
