@@ -285,6 +285,43 @@ def test_attention(B, H, HD, Lq, Lk, l2norm, split):
             assert errp < 2e-5, errp
 
 
+_RES_CHILD = r"""
+import ctypes as C, sys, math, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from artalk_amd import capi
+L = capi.lib()
+p = lambda t: C.c_void_p(t.data_ptr())
+M, N, K, cfg = [int(x) for x in sys.argv[3:7]]
+g = torch.Generator().manual_seed(5)
+A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g); R = torch.randn(M, N, generator=g)
+dA, dW, db, out = A.cuda(), W.cuda(), b.cuda(), R.cuda()
+Ap = torch.empty(M, K, dtype=torch.int32, device="cuda"); Wp = torch.empty(N, K, dtype=torch.int32, device="cuda")
+assert L.artalk_op_pack_split(p(dA), p(Ap), M * K, 0, None) == 0 and L.artalk_op_pack_split(p(dW), p(Wp), N * K, 1, None) == 0
+assert L.artalk_op_gemm_f16s_packed(p(Ap), 1, K, p(Wp), p(db), p(out), M, N, K, 0x200, cfg, None) == 0      # 0x200: residual read from C, in place
+torch.cuda.synchronize()
+ref = R.double() + A.double() @ W.double().t() + b.double()
+err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+assert err < 2e-6, err
+np.save(sys.argv[2], out.cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize("M,N,K,cfg", [(19200 // 4 + 77, 1024, 1024, 9), (2000, 1024, 4096, 9), (8192 + 77, 1024, 1024, 99)])
+def test_persistent_gemm_residual_deferred_equals_immediate(tmp_path, M, N, K, cfg):
+    """Residual tiles of gemm_p8_2wgp_kernel (the encoder's out-projection / FFN-out, x += ... in place): correct against float64 and
+    bit-identical whether the residual sub-tiles are deferred through the LDS-DMA slots (default) or finished at once
+    (ARTALK_P8_RES_DEFER=0).  The switch is read once per process: one child per arm."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for defer in ("1", "0"):
+        f = str(tmp_path / f"res{defer}.npy")
+        env = dict(os.environ, ARTALK_P8_RES_DEFER=defer)
+        subprocess.run([sys.executable, "-c", _RES_CHILD, root, f, str(M), str(N), str(K), str(cfg)], check=True, env=env, timeout=300)
+        outs.append(np.load(f))
+    assert np.array_equal(outs[0], outs[1])
+
+
 _WIDE_CHILD = r"""
 import ctypes as C, sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
