@@ -507,7 +507,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        constexpr int GM = 2;
+        const int GM = g.tile_gm > 0 ? g.tile_gm : 8;      // row tiles per XCD tile group (tuning: ARTALK_P8_256_GM; 8 x 4 tiles per XCD measured 0.27 ms per step better than 2 x 16)
         const int width = GM * tiles_n;
         const int group = idx / width, first_m = group * GM;
         const int gsz = min(tiles_m - first_m, GM);
@@ -1655,7 +1655,13 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
         case 5: hipLaunchKernelGGL((gemm_p8_kernel<128, 5>), dim3(t128), dim3(512), 5 * 256 * 128, s, g); break;
         case 6: hipLaunchKernelGGL((gemm_p8_kernel<256, 3>), dim3(t256), dim3(512), 3 * 384 * 128, s, g); break;
         case 16: hipLaunchKernelGGL((gemm_p8_kernel<128, 4, 6>), dim3(t128), dim3(512), 4 * 256 * 128, s, g); break;
-        case 7: hipLaunchKernelGGL((gemm_p8_256_kernel<0>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
+        case 7: {
+            static const int gm256 = getenv("ARTALK_P8_256_GM") ? atoi(getenv("ARTALK_P8_256_GM")) : 0;
+            GemmArgs a = g;
+            a.tile_gm = gm256;
+            hipLaunchKernelGGL((gemm_p8_256_kernel<0>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, a);
+            break;
+        }
         case 17: hipLaunchKernelGGL((gemm_p8_256_kernel<6>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
         case 10: hipLaunchKernelGGL((gemm_p8_256_kernel<1>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;   // tuning: direct-store epilogue
         case 18: hipLaunchKernelGGL((gemm_p8_2wg_kernel<6>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;
