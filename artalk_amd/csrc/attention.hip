@@ -793,7 +793,7 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
     // v_exp_f32-based exp (1.2e-6 relative at |x| = 20, where p = 2e-9) by default: 154 -> 137 us per wav2vec2 layer; the fp32 kernels keep expf
     static const int fastexp = getenv("ARTALK_ATTN_FASTEXP") ? atoi(getenv("ARTALK_ATTN_FASTEXP")) : 1;
     static const int wide = getenv("ARTALK_ATTN_WIDE") ? atoi(getenv("ARTALK_ATTN_WIDE")) : 1;      // tuning: 0 = 64-query workgroups everywhere
-    if (a.HD == 64 && a.split16 && a.qkv_p8 && !a.l2norm && wide && a.Lq <= kWideMaxWaves * 16 && a.Lk <= kWideMaxKeys &&
+    if (a.HD == 64 && a.split16 && a.qkv_p8 && !a.l2norm && wide && a.Lq > 128 && a.Lq <= kWideMaxWaves * 16 && a.Lk <= kWideMaxKeys &&      // (100 queries: 7.2 vs 6.4 us, the two-workgroup form wins)
         (long)a.B * a.H >= wide_min_heads()) {
         const size_t lds = (size_t)4 * ((a.Lk + 31) & ~31) * 160;
         attention_prepare();
