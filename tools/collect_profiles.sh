@@ -5,9 +5,6 @@ R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 rm -rf $O && mkdir -p $O
-echo "== unprofiled default bench"
-timeout -k 10 500 python bench.py --steps 20 --warmup 5 2>$O/bench.err | tail -1 > $O/bench_line.json
-cut -c1-400 $O/bench_line.json
 echo "== kernel trace f16x3"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_f16x3 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-mode > $O/kt_f16x3.log 2>&1
 python tools/summarize_profile.py stats $O/kt_f16x3 $O/f16x3_kernel_stats.csv > /dev/null
@@ -34,6 +31,10 @@ echo "== pmc write"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-mode > $O/pmc_write.log 2>&1
 python tools/summarize_profile.py pmc $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json | head -12
 find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete
+echo "== unprofiled default bench (after the PMC passes: its roofline.traffic is read from THIS run's pmc_traffic.json)"
+cp $O/pmc_traffic.json profiles/${R}_pmc_traffic.json
+timeout -k 10 500 python bench.py --steps 20 --warmup 5 2>$O/bench.err | tail -1 > $O/bench_line.json
+cut -c1-400 $O/bench_line.json
 echo "== gemm microbenchmarks"
 GEMM_GRAPH=0 GEMM_VARIANTS="1:1,2:1,7:1,8:1,99:1" GEMM_ONLY="w2v qkv,w2v out,w2v ff1,w2v ff2,conv1,ada" timeout -k 10 200 python tools/gemm_f16s_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_f16s_bench.log
 timeout -k 10 100 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > $O/attn_bench.log
