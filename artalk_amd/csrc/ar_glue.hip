@@ -172,25 +172,40 @@ __global__ __launch_bounds__(256) void vq_embed_kernel(const float* __restrict__
     }
     const int nt = min(VQ_TOK, n - i0);
     for (int idx = tid; idx < VQ_TOK * CD; idx += 256) f[idx / CD][idx % CD] = idx < nt * CD ? feat[((long)b * n + i0) * CD + idx] : 0.f;
-    __syncthreads();
-    for (int e = tid; e < E; e += 256) {
-        float w[CD];
+    // every global load of this thread - three weight rows, their biases and the position rows of all 16 tokens - is issued before
+    // the first use: the position loads used to sit inside the token loop, twelve exposed latencies per workgroup (22 us per launch)
+    constexpr int EPT = 3;                       // E = 768 = 3 x 256 threads (guarded for a smaller E)
+    float w[EPT][CD], bias[EPT], pv[EPT][VQ_TOK];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * 256;
+        const bool ok = e < E;
 #pragma unroll
         for (int c4 = 0; c4 < CD / 4; ++c4) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(We + (long)e * CD + 4 * c4);
-            w[4 * c4] = t[0]; w[4 * c4 + 1] = t[1]; w[4 * c4 + 2] = t[2]; w[4 * c4 + 3] = t[3];
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (ok) t = *reinterpret_cast<const f32x4*>(We + (long)e * CD + 4 * c4);
+            w[k][4 * c4] = t[0]; w[k][4 * c4 + 1] = t[1]; w[k][4 * c4 + 2] = t[2]; w[k][4 * c4 + 3] = t[3];
         }
-        const float bias = be[e];
-        // four tokens at a time: four independent 32-long fma chains in flight instead of one (each token's own order is unchanged)
-        for (int t0 = 0; t0 < nt; t0 += 4) {
+        bias[k] = ok ? be[e] : 0.f;
+#pragma unroll
+        for (int t = 0; t < VQ_TOK; ++t) pv[k][t] = (ok && t < nt) ? pos[(long)(i0 + t) * E + e] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * 256;
+        if (e >= E) break;
+        // four tokens at a time: four independent 32-long fma chains in flight (each token's own order is unchanged: bit-identical)
+#pragma unroll
+        for (int t0 = 0; t0 < VQ_TOK; t0 += 4) {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < CD; ++c)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] = fmaf(w[c], f[min(t0 + u, VQ_TOK - 1)][c], acc[u]);
+                for (int u = 0; u < 4; ++u) acc[u] = fmaf(w[k][c], f[t0 + u][c], acc[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (t0 + u < nt) X[((long)b * xrows + xoff + i0 + t0 + u) * E + e] = (acc[u] + bias) + pos[(long)(i0 + t0 + u) * E + e];
+                if (t0 + u < nt) X[((long)b * xrows + xoff + i0 + t0 + u) * E + e] = (acc[u] + bias[k]) + pv[k][t0 + u];
         }
     }
 }
