@@ -275,15 +275,17 @@ void launch_enc_input_zero(const float* mean, const float* stdv, const float* ep
 }
 
 // ------------------------------------------------------------------------------------------------
-// One workgroup per clip.  Sequential over the 5 scales (each needs the residual left by the previous one).
-__global__ __launch_bounds__(256) void bsq_history_kernel(const float* __restrict__ enc_out, uint8_t* __restrict__ hist_bits,
+// One workgroup per clip.  Sequential over the 5 scales (each needs the residual left by the previous one); 1024 threads: the kernel is a
+// chain of passes over the clip's 3 200 values between barriers, 3 trips per pass instead of 13 (41 -> ~20 us per launch).
+constexpr int BSQ_NT = 1024;
+__global__ __launch_bounds__(BSQ_NT) void bsq_history_kernel(const float* __restrict__ enc_out, uint8_t* __restrict__ hist_bits,
                                                           float* __restrict__ prev_fdec, float* __restrict__ msfeat, int* __restrict__ status) {
     __shared__ float resid[T100 * CD];
     __shared__ float fms[T100 * CD];     // sum of up(h_p), the feature recurrence from bits
     __shared__ float qs[T100 * CD];      // quantised values q = z + (zhat - z) of this scale
     __shared__ float hs[T100 * CD];      // +-1/sqrt(32) from the bits of this scale
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int idx = tid; idx < T100 * CD; idx += 256) {
+    for (int idx = tid; idx < T100 * CD; idx += BSQ_NT) {
         resid[idx] = enc_out[(long)b * T100 * CD + idx];
         if (status && !isfinite(resid[idx])) atomicOr(status, 2);
         fms[idx] = 0.f;
@@ -292,8 +294,8 @@ __global__ __launch_bounds__(256) void bsq_history_kernel(const float* __restric
     int msoff = 0;
     for (int p = 0; p < NLV; ++p) {
         const int pn = c_pn[p], off = c_off[p];
-        // all 256 threads run the loop body the same number of times (3200 % 256 != 0 -> guard inside, shuffles outside)
-        for (int base = 0; base < pn * CD; base += 256) {
+        // all threads run the loop body the same number of times (guard inside, shuffles outside)
+        for (int base = 0; base < pn * CD; base += BSQ_NT) {
             const int idx = base + tid;
             const bool ok = idx < pn * CD;
             const int i = ok ? idx / CD : 0, c = idx % CD;
@@ -314,24 +316,24 @@ __global__ __launch_bounds__(256) void bsq_history_kernel(const float* __restric
         }
         __syncthreads();
         if (p < NLV - 1) {
-            for (int idx = tid; idx < T100 * CD; idx += 256) {
+            for (int idx = tid; idx < T100 * CD; idx += BSQ_NT) {
                 const int t = idx / CD, c = idx % CD;
                 resid[idx] -= up_lin(qs, p, t, c);
                 fms[idx] += up_lin(hs, p, t, c);
             }
             __syncthreads();
             const int pn2 = c_pn[p + 1];
-            for (int idx = tid; idx < pn2 * CD; idx += 256)
+            for (int idx = tid; idx < pn2 * CD; idx += BSQ_NT)
                 msfeat[((long)b * 180 + msoff) * CD + idx] = area_pool(fms, pn2, idx / CD, idx % CD);
             msoff += pn2;
         } else {
-            for (int idx = tid; idx < T100 * CD; idx += 256) prev_fdec[(long)b * T100 * CD + idx] = fms[idx] + hs[idx];
+            for (int idx = tid; idx < T100 * CD; idx += BSQ_NT) prev_fdec[(long)b * T100 * CD + idx] = fms[idx] + hs[idx];
         }
         __syncthreads();
     }
 }
 void launch_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fdec, float* msfeat, int B, hipStream_t s, int* status) {
-    hipLaunchKernelGGL(bsq_history_kernel, dim3(B), dim3(256), 0, s, enc_out, hist_bits, prev_fdec, msfeat, status);
+    hipLaunchKernelGGL(bsq_history_kernel, dim3(B), dim3(BSQ_NT), 0, s, enc_out, hist_bits, prev_fdec, msfeat, status);
 }
 
 // ------------------------------------------------------------------------------------------------
