@@ -121,13 +121,14 @@ void launch_ar_begin(const float* style_cond, const float* lvlpos, float* x0, fl
 
 // ------------------------------------------------------------------------------------------------
 // level p: logits rows b*pn+i -> bits; f_hat += up(h_p); nextfeat[b, i', :] = area(f_hat -> pn[p+1])
-__global__ __launch_bounds__(256) void ar_bits_kernel(const float* __restrict__ logits, uint8_t* __restrict__ bits,
+constexpr int BITS_NT = 1024;      // passes over the clip's <= 3 200 values between barriers: 3 trips instead of 13
+__global__ __launch_bounds__(BITS_NT) void ar_bits_kernel(const float* __restrict__ logits, uint8_t* __restrict__ bits,
                                                       float* __restrict__ fhat, float* __restrict__ nextfeat, int p, int* __restrict__ status) {
     __shared__ float hs[T100 * CD];
     __shared__ float fs[T100 * CD];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int pn = c_pn[p], off = c_off[p];
-    for (int idx = tid; idx < pn * CD; idx += 256) {
+    for (int idx = tid; idx < pn * CD; idx += BITS_NT) {
         const int i = idx / CD, c = idx % CD;
         const float* l = logits + ((long)b * pn + i) * (2 * CD) + 2 * c;
         const int bit = l[1] > l[0];                       // argmax over the pair, ties -> 0
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void ar_bits_kernel(const float* __restrict__ 
     if (p >= NLV - 1) return;
     __syncthreads();
     float* fg = fhat + (long)b * T100 * CD;
-    for (int idx = tid; idx < T100 * CD; idx += 256) {
+    for (int idx = tid; idx < T100 * CD; idx += BITS_NT) {
         const int t = idx / CD, c = idx % CD;
         const float v = fg[idx] + up_lin(hs, p, t, c);
         fg[idx] = v;
@@ -147,11 +148,11 @@ __global__ __launch_bounds__(256) void ar_bits_kernel(const float* __restrict__ 
     }
     __syncthreads();
     const int pn2 = c_pn[p + 1];
-    for (int idx = tid; idx < pn2 * CD; idx += 256)
+    for (int idx = tid; idx < pn2 * CD; idx += BITS_NT)
         nextfeat[(long)b * pn2 * CD + idx] = area_pool(fs, pn2, idx / CD, idx % CD);
 }
 void launch_ar_bits_next(const float* logits, uint8_t* bits, float* fhat, float* nextfeat, int B, int level, hipStream_t s, int* status) {
-    hipLaunchKernelGGL(ar_bits_kernel, dim3(B), dim3(256), 0, s, logits, bits, fhat, nextfeat, level, status);
+    hipLaunchKernelGGL(ar_bits_kernel, dim3(B), dim3(BITS_NT), 0, s, logits, bits, fhat, nextfeat, level, status);
 }
 
 // ------------------------------------------------------------------------------------------------
