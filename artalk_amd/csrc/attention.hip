@@ -769,6 +769,217 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
     }
 }
 
+// ---- The same idea for the 100-query scale step of the AR decoder (fp32 q | k | v rows of the KV cache, L2-normalised q and k,
+// 362 keys): one workgroup of 7 waves per (clip, head) stages 192 keys at a time (K and V, hi and lo images: 120 KB) - two staging
+// round trips per head instead of six per 64-query workgroup, and the normalise + split work of a key done once instead of twice.
+// Waves walk attention_f16_kernel<.., 0>'s 64-key blocks in the same order with the same arithmetic: bit-identical results.
+constexpr int kWideArWaves = 7, kWideArKeys = 192;
+template <int FASTEXP>
+__global__ __launch_bounds__(kWideArWaves * 64) void attention_f16_wide_ar_kernel(const AttnArgs a) {
+    constexpr int HD = 64, KB = 64, PB = 160, NT = kWideArWaves * 64, KPH = kWideArKeys;
+    constexpr int NPASS = (KPH * 16 + NT - 1) / NT;      // 7
+    extern __shared__ __attribute__((aligned(16))) unsigned char wide_smem[];
+    unsigned char* const Kh = wide_smem;
+    unsigned char* const Kl = Kh + KPH * PB;
+    unsigned char* const Vh = Kl + KPH * PB;
+    unsigned char* const Vl = Vh + KPH * PB;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = wave * 16;
+    const int qi = q0 + r;
+    const bool qvalid = qi < a.Lq;
+    const bool wave_active = q0 < a.Lq;
+
+    // ---- Q fragments (B operand of S^T): lane (r, g) holds Q[qi][8g + 32kb .. +7], normalised, scaled, split ----
+    h8_t qh[2], ql[2];
+    {
+        const float* qp = a.Q + (long)b * a.q_bstride + (long)min(qi, a.Lq - 1) * a.ldq + h * HD;
+        f32x4 x[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 t = *reinterpret_cast<const f32x4*>(qp + 8 * g + 32 * kb + 4 * u);
+                x[kb][u] = qvalid ? t : z;
+            }
+        if (a.l2norm) {
+            float ss = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ss += x[kb][u][e] * x[kb][u][e];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float den = fmaxf(sqrtf(ss), 1e-12f);
+            const float mul = a.qscale[h];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[kb][u][e] = (x[kb][u][e] / den) * mul;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f16x4_t h0, l0, h1, l1;
+            split4(x[kb][0] * a.scale, h0, l0);
+            split4(x[kb][1] * a.scale, h1, l1);
+            qh[kb] = h8_t{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            ql[kb] = h8_t{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        }
+    }
+    const int klim = a.Lk;                       // (no split mask on this path: launch_attention)
+    float m_run = -INFINITY, l_part = 0.f;
+    f32x4 ot[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; ot[d] = z; }
+    const float* Kb = a.K + (long)b * a.k_bstride + h * HD;
+    const float* Vb = a.V + (long)b * a.v_bstride + h * HD;
+    const int trq = r >> 2, trp = r & 3;
+
+    for (int k0 = 0; k0 < a.Lk; k0 += KPH) {
+        __syncthreads();                         // every wave is done with the previous phase's rows
+        {   // stage keys k0 .. k0 + KPH - 1: 16 threads per key row, all loads first
+            f32x4 kv[NPASS], vv[NPASS];
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const int idx = tid + i * NT;
+                const int row = idx >> 4, c4 = (idx & 15) * 4;
+                const int kr = k0 + row;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                kv[i] = z; vv[i] = z;
+                if (row < KPH && kr < a.Lk) {
+                    kv[i] = *reinterpret_cast<const f32x4*>(Kb + (long)kr * a.ldk + c4);
+                    vv[i] = *reinterpret_cast<const f32x4*>(Vb + (long)kr * a.ldv + c4);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const int idx = tid + i * NT;
+                const int row = idx >> 4, c4 = (idx & 15) * 4;
+                f32x4 kx = kv[i];
+                if (a.l2norm) {
+                    float ss = kx[0] * kx[0] + kx[1] * kx[1] + kx[2] * kx[2] + kx[3] * kx[3];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                    const float den = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) kx[e] = kx[e] / den;
+                }
+                if (row < KPH) {
+                    f16x4_t hh, ll;
+                    split4(kx, hh, ll);
+                    *reinterpret_cast<f16x4_t*>(Kh + row * PB + c4 * 2) = hh;
+                    *reinterpret_cast<f16x4_t*>(Kl + row * PB + c4 * 2) = ll;
+                    split4(vv[i], hh, ll);
+                    *reinterpret_cast<f16x4_t*>(Vh + row * PB + c4 * 2) = hh;
+                    *reinterpret_cast<f16x4_t*>(Vl + row * PB + c4 * 2) = ll;
+                }
+            }
+        }
+        __syncthreads();
+        if (!wave_active) continue;              // wave-uniform
+        const int kend = min(k0 + KPH, a.Lk);
+        for (int kb0 = k0; kb0 < kend; kb0 += KB) {
+            const int lb = kb0 - k0;             // first LDS row of this block
+            const int ntile = min(4, (a.Lk - kb0 + 15) >> 4);
+            f32x4 st[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (t < ntile) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const int off = (lb + t * 16 + r) * PB + (8 * g + 32 * kb) * 2;
+                        const h8_t kh2 = *reinterpret_cast<const h8_t*>(Kh + off), kl2 = *reinterpret_cast<const h8_t*>(Kl + off);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh2, qh[kb], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl2, qh[kb], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh2, ql[kb], acc, 0, 0, 0);
+                    }
+                }
+                st[t] = acc;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kidx = kb0 + t * 16 + 4 * g + j;
+                    const float sv = (kidx < klim) ? st[t][j] : -INFINITY;
+                    st[t][j] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = FASTEXP ? __expf(m_run - m_safe) : expf(m_run - m_safe);
+            m_run = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p = FASTEXP ? __expf(st[t][j] - m_safe) : expf(st[t][j] - m_safe);
+                    st[t][j] = p;
+                    ps += p;
+                }
+            l_part = l_part * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) ot[d] *= alpha;
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                if (2 * T < ntile) {
+                    f16x4_t h0, l0, h1, l1;
+                    split4(st[2 * T], h0, l0);
+                    split4(st[2 * T + 1], h1, l1);
+                    const h8_t ph = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    const h8_t pl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                    const int row1 = lb + T * 32 + 4 * g + trq, row2 = row1 + 16;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const int col = (16 * dt + 4 * trp) * 2;
+                        const f16x4_t a1 = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_raw*)(Vh + row1 * PB + col)));
+                        const f16x4_t a2 = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_raw*)(Vh + row2 * PB + col)));
+                        const f16x4_t b1 = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_raw*)(Vl + row1 * PB + col)));
+                        const f16x4_t b2 = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_raw*)(Vl + row2 * PB + col)));
+                        const h8_t vh2 = {a1[0], a1[1], a1[2], a1[3], a2[0], a2[1], a2[2], a2[3]};
+                        const h8_t vl2 = {b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3]};
+                        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh2, ph, ot[dt], 0, 0, 0);
+                        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl2, ph, ot[dt], 0, 0, 0);
+                        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh2, pl, ot[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (!wave_active) return;
+    float l = l_part;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qvalid) {
+        const float inv = 1.0f / l;
+        float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            const float o0 = ot[dt][0] * inv, o1 = ot[dt][1] * inv, o2 = ot[dt][2] * inv, o3 = ot[dt][3] * inv;
+            if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status);
+            else { const f32x4 o = {o0, o1, o2, o3}; *reinterpret_cast<f32x4*>(op + d0) = o; }
+        }
+    }
+}
+
 void attention_prepare() {      // more than the default 64 KB of dynamic LDS for the wide kernel; called at model creation (outside any capture)
     static bool done[64] = {};      // per device: the attribute belongs to the function on the current device
     int dev = 0;
@@ -776,6 +987,8 @@ void attention_prepare() {      // more than the default 64 KB of dynamic LDS fo
     if (dev < 0 || dev >= 64 || done[dev]) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               4 * kWideMaxKeys * 160);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_wide_ar_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              4 * kWideArKeys * 160);
     done[dev] = true;
 }
 static long wide_min_heads() {      // tuning: fewest (clip, head) pairs for which one workgroup per pair is taken
@@ -800,7 +1013,10 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((attention_f16_wide_kernel<1>), dim3(1, a.H, a.B), dim3(kWideMaxWaves * 64), lds, s, a);
     } else if (a.HD == 64 && a.split16 && a.qkv_p8 && !a.l2norm)
         hipLaunchKernelGGL((attention_f16_kernel<1, 1>), grid, block, 0, s, a);
-    else if (a.HD == 64 && a.split16 && fastexp)
+    else if (a.HD == 64 && a.split16 && fastexp && wide && !a.qkv_p8 && a.split_q == 0 && a.Lq > 32 && a.Lq <= kWideArWaves * 16 && a.Lk > 64) {
+        attention_prepare();      // the 100-query scale step of the AR decoder: one workgroup per (clip, head), 192 keys per staging phase
+        hipLaunchKernelGGL((attention_f16_wide_ar_kernel<1>), dim3(1, a.H, a.B), dim3(kWideArWaves * 64), (size_t)4 * kWideArKeys * 160, s, a);
+    } else if (a.HD == 64 && a.split16 && fastexp)
         hipLaunchKernelGGL(attention_f16_kernel<1>, grid, block, 0, s, a);
     else if (a.HD == 64 && a.split16)
         hipLaunchKernelGGL(attention_f16_kernel<0>, grid, block, 0, s, a);

@@ -329,32 +329,39 @@ from artalk_amd import capi
 L = capi.lib()
 p = lambda t: C.c_void_p(t.data_ptr())
 B, H, HD, Lq, Lk, split = [int(x) for x in sys.argv[3:9]]
+ar = sys.argv[9] == "ar"
 g = torch.Generator().manual_seed(77)
 D = H * HD
-pk = []
-for n in (Lq, Lk, Lk):
-    t = torch.randn(B, n, D, generator=g).cuda()
-    o = torch.empty_like(t, dtype=torch.int32)
-    assert L.artalk_op_pack_split(p(t), p(o), t.numel(), 0, None) == 0
-    pk.append(o)
+ts = [torch.randn(B, n, D, generator=g).cuda() for n in (Lq, Lk, Lk)]
 out = torch.full((B, Lq, D), float("nan"), device="cuda")
-assert L.artalk_op_attention(p(pk[0]), p(pk[1]), p(pk[2]), p(out), B, H, HD, Lq, Lk, 0.125, 2 | 4, None, split, None) == 0
+if ar:      # fp32 rows, L2-normalised q and k with a per-head scale: the AR decoder's attention (f16 operand-split kernels)
+    qs = (torch.rand(H, generator=g) * 4 + 1).cuda()
+    assert L.artalk_op_attention(p(ts[0]), p(ts[1]), p(ts[2]), p(out), B, H, HD, Lq, Lk, 1.0, 1 | 2, p(qs), 0, None) == 0
+else:       # P8 rows as the qkv GEMM hands them over (wav2vec2 encoder, VAE stacks)
+    pk = []
+    for t in ts:
+        o = torch.empty_like(t, dtype=torch.int32)
+        assert L.artalk_op_pack_split(p(t), p(o), t.numel(), 0, None) == 0
+        pk.append(o)
+    assert L.artalk_op_attention(p(pk[0]), p(pk[1]), p(pk[2]), p(out), B, H, HD, Lq, Lk, 0.125, 2 | 4, None, split, None) == 0
 torch.cuda.synchronize()
 np.save(sys.argv[2], out.cpu().numpy())
 """
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,split", [(3, 16, 199, 199, 0), (2, 8, 200, 200, 100), (2, 8, 100, 100, 0)])
-def test_attention_wide_kernel_is_bit_identical(tmp_path, B, H, Lq, Lk, split):
-    """attention_f16_wide_kernel (one workgroup per (clip, head), all keys staged once) must give bit for bit what the 64-query
-    kernel gives: the switch is read once per process, so each arm runs in a child process (ARTALK_ATTN_WIDE=1 / 0)."""
+@pytest.mark.parametrize("B,H,Lq,Lk,split,mode", [(3, 16, 199, 199, 0, "p8"), (2, 8, 200, 200, 100, "p8"), (2, 8, 100, 100, 0, "p8"),
+                                                  (3, 12, 100, 362, 0, "ar"), (2, 12, 97, 181, 0, "ar")])
+def test_attention_wide_kernel_is_bit_identical(tmp_path, B, H, Lq, Lk, split, mode):
+    """attention_f16_wide_kernel / attention_f16_wide_ar_kernel (one workgroup per (clip, head), keys staged once / 192 at a time)
+    must give bit for bit what the 64-query kernel gives: the switch is read once per process, so each arm runs in a child process
+    (ARTALK_ATTN_WIDE=1 / 0)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for wide in ("1", "0"):
         f = str(tmp_path / f"wide{wide}.npy")
         env = dict(os.environ, ARTALK_ATTN_WIDE=wide)
-        subprocess.run([sys.executable, "-c", _WIDE_CHILD, root, f, str(B), str(H), "64", str(Lq), str(Lk), str(split)], check=True, env=env,
+        subprocess.run([sys.executable, "-c", _WIDE_CHILD, root, f, str(B), str(H), "64", str(Lq), str(Lk), str(split), mode], check=True, env=env,
                        timeout=300)
         outs.append(np.load(f))
     assert np.isfinite(outs[0]).all()
