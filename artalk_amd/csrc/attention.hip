@@ -774,9 +774,10 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
 // round trips per head instead of six per 64-query workgroup, and the normalise + split work of a key done once instead of twice.
 // Waves walk attention_f16_kernel<.., 0>'s 64-key blocks in the same order with the same arithmetic: bit-identical results.
 constexpr int kWideArWaves = 7, kWideArKeys = 192;
-template <int FASTEXP>
-__global__ __launch_bounds__(kWideArWaves * 64) void attention_f16_wide_ar_kernel(const AttnArgs a) {
-    constexpr int HD = 64, KB = 64, PB = 160, NT = kWideArWaves * 64, KPH = kWideArKeys;
+// QKVP8 = 1: q, k, v rows in the P8 format (no normalisation; the encoder / VAE form), several workgroups of NW waves per head.
+template <int FASTEXP, int QKVP8 = 0, int NW = kWideArWaves, int KPH = kWideArKeys>
+__global__ __launch_bounds__(NW * 64) void attention_f16_wide_ar_kernel(const AttnArgs a) {
+    constexpr int HD = 64, KB = 64, PB = 160, NT = NW * 64;
     constexpr int NPASS = (KPH * 16 + NT - 1) / NT;      // 7
     extern __shared__ __attribute__((aligned(16))) unsigned char wide_smem[];
     unsigned char* const Kh = wide_smem;
@@ -787,14 +788,23 @@ __global__ __launch_bounds__(kWideArWaves * 64) void attention_f16_wide_ar_kerne
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = wave * 16;
+    const int q0 = blockIdx.x * (NW * 16) + wave * 16;
     const int qi = q0 + r;
     const bool qvalid = qi < a.Lq;
     const bool wave_active = q0 < a.Lq;
 
     // ---- Q fragments (B operand of S^T): lane (r, g) holds Q[qi][8g + 32kb .. +7], normalised, scaled, split ----
     h8_t qh[2], ql[2];
-    {
+    if constexpr (QKVP8) {
+        const unsigned char* qp = reinterpret_cast<const unsigned char*>(a.Q + (long)b * a.q_bstride + (long)min(qi, a.Lq - 1) * a.ldq + h * HD);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            const h8_t th = *reinterpret_cast<const h8_t*>(qp + (g + 4 * kb) * 32), tl = *reinterpret_cast<const h8_t*>(qp + (g + 4 * kb) * 32 + 16);
+            qh[kb] = qvalid ? th : z;
+            ql[kb] = qvalid ? tl : z;
+        }
+    } else {
         const float* qp = a.Q + (long)b * a.q_bstride + (long)min(qi, a.Lq - 1) * a.ldq + h * HD;
         f32x4 x[2][2];
 #pragma unroll
@@ -833,7 +843,13 @@ __global__ __launch_bounds__(kWideArWaves * 64) void attention_f16_wide_ar_kerne
             ql[kb] = h8_t{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
         }
     }
-    const int klim = a.Lk;                       // (no split mask on this path: launch_attention)
+    const float sfix = QKVP8 ? a.scale / (kActScale * kActScale) : 1.0f;      // scores of P8 operands carry 16 * 16 and no softmax scale yet
+    const int klim = (a.split_q > 0 && qi < a.split_q) ? a.split_k : a.Lk;
+    // the 64-query workgroup of attention_f16_kernel this wave's queries belong to decides how far its key loop runs there: the same
+    // bound here keeps the block sequence of a query identical; the phase loop runs to the furthest bound of the workgroup's waves
+    const int lk_wave = (a.split_q > 0 && min((q0 & ~63) + 63, a.Lq - 1) < a.split_q) ? a.split_k : a.Lk;
+    const int wg_last = min((int)(blockIdx.x + 1) * (NW * 16) - 1, a.Lq - 1);
+    const int lk_loop = (a.split_q > 0 && wg_last < a.split_q) ? a.split_k : a.Lk;
     float m_run = -INFINITY, l_part = 0.f;
     f32x4 ot[4];
 #pragma unroll
@@ -842,8 +858,38 @@ __global__ __launch_bounds__(kWideArWaves * 64) void attention_f16_wide_ar_kerne
     const float* Vb = a.V + (long)b * a.v_bstride + h * HD;
     const int trq = r >> 2, trp = r & 3;
 
-    for (int k0 = 0; k0 < a.Lk; k0 += KPH) {
+    for (int k0 = 0; k0 < lk_loop; k0 += KPH) {
         __syncthreads();                         // every wave is done with the previous phase's rows
+        if constexpr (QKVP8) {      // one 8-element group (16 B hi + 16 B lo) of K and of V per thread and pass: plain copies
+            constexpr int NP8 = (KPH * 8 + NT - 1) / NT;
+            h8_t kh[NP8], kl[NP8], vh[NP8], vl[NP8];
+#pragma unroll
+            for (int i = 0; i < NP8; ++i) {
+                const int idx = tid + i * NT;
+                const int row = idx >> 3, g8 = idx & 7;
+                const int kr = k0 + row;
+                const h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+                kh[i] = z; kl[i] = z; vh[i] = z; vl[i] = z;
+                if (row < KPH && kr < a.Lk) {
+                    const unsigned char* kp = reinterpret_cast<const unsigned char*>(Kb + (long)kr * a.ldk) + g8 * 32;
+                    const unsigned char* vp = reinterpret_cast<const unsigned char*>(Vb + (long)kr * a.ldv) + g8 * 32;
+                    kh[i] = *reinterpret_cast<const h8_t*>(kp); kl[i] = *reinterpret_cast<const h8_t*>(kp + 16);
+                    vh[i] = *reinterpret_cast<const h8_t*>(vp); vl[i] = *reinterpret_cast<const h8_t*>(vp + 16);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NP8; ++i) {
+                const int idx = tid + i * NT;
+                const int row = idx >> 3, g8 = idx & 7;
+                if (row < KPH) {
+                    *reinterpret_cast<h8_t*>(Kh + row * PB + g8 * 16) = kh[i];
+                    *reinterpret_cast<h8_t*>(Kl + row * PB + g8 * 16) = kl[i];
+                    *reinterpret_cast<h8_t*>(Vh + row * PB + g8 * 16) = vh[i];
+                    *reinterpret_cast<h8_t*>(Vl + row * PB + g8 * 16) = vl[i];
+                }
+            }
+        } else
         {   // stage keys k0 .. k0 + KPH - 1: 16 threads per key row, all loads first
             f32x4 kv[NPASS], vv[NPASS];
 #pragma unroll
@@ -885,7 +931,7 @@ __global__ __launch_bounds__(kWideArWaves * 64) void attention_f16_wide_ar_kerne
         }
         __syncthreads();
         if (!wave_active) continue;              // wave-uniform
-        const int kend = min(k0 + KPH, a.Lk);
+        const int kend = min(k0 + KPH, lk_wave);
         for (int kb0 = k0; kb0 < kend; kb0 += KB) {
             const int lb = kb0 - k0;             // first LDS row of this block
             const int ntile = min(4, (a.Lk - kb0 + 15) >> 4);
@@ -911,7 +957,7 @@ __global__ __launch_bounds__(kWideArWaves * 64) void attention_f16_wide_ar_kerne
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int kidx = kb0 + t * 16 + 4 * g + j;
-                    const float sv = (kidx < klim) ? st[t][j] : -INFINITY;
+                    const float sv = (kidx < klim) ? (QKVP8 ? st[t][j] * sfix : st[t][j]) : -INFINITY;
                     st[t][j] = sv;
                     mx = fmaxf(mx, sv);
                 }
@@ -968,7 +1014,7 @@ __global__ __launch_bounds__(kWideArWaves * 64) void attention_f16_wide_ar_kerne
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (qvalid) {
-        const float inv = 1.0f / l;
+        const float inv = QKVP8 ? 1.0f / (l * kActScale) : 1.0f / l;      // P8 values carry x16
         float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -989,6 +1035,8 @@ void attention_prepare() {      // more than the default 64 KB of dynamic LDS fo
                               4 * kWideMaxKeys * 160);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_wide_ar_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               4 * kWideArKeys * 160);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_wide_ar_kernel<1, 1, 7, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              4 * 128 * 160);
     done[dev] = true;
 }
 static long wide_min_heads() {      // tuning: fewest (clip, head) pairs for which one workgroup per pair is taken
@@ -1010,7 +1058,10 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         (long)a.B * a.H >= wide_min_heads()) {
         const size_t lds = (size_t)4 * ((a.Lk + 31) & ~31) * 160;
         attention_prepare();
-        hipLaunchKernelGGL((attention_f16_wide_kernel<1>), dim3(1, a.H, a.B), dim3(kWideMaxWaves * 64), lds, s, a);
+        // fewer (clip, head) pairs than CUs (the VAE stacks of one clip group: 128): two 7-wave workgroups per head, 128 keys per phase
+        // (14.1 -> 11.9 us); the encoder's 1536 pairs run the same either way (109 us: bound by the softmax arithmetic, not by staging)
+        if (wide == 2 || (long)a.B * a.H < 256) hipLaunchKernelGGL((attention_f16_wide_ar_kernel<1, 1, 7, 128>), dim3((a.Lq + 111) / 112, a.H, a.B), dim3(7 * 64), (size_t)4 * 128 * 160, s, a);
+        else hipLaunchKernelGGL((attention_f16_wide_kernel<1>), dim3(1, a.H, a.B), dim3(kWideMaxWaves * 64), lds, s, a);
     } else if (a.HD == 64 && a.split16 && a.qkv_p8 && !a.l2norm)
         hipLaunchKernelGGL((attention_f16_kernel<1, 1>), grid, block, 0, s, a);
     else if (a.HD == 64 && a.split16 && fastexp && wide && !a.qkv_p8 && a.split_q == 0 && a.Lq > 32 && a.Lq <= kWideArWaves * 16 && a.Lk > 64) {

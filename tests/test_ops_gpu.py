@@ -349,7 +349,7 @@ np.save(sys.argv[2], out.cpu().numpy())
 """
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,split,mode", [(3, 16, 199, 199, 0, "p8"), (2, 8, 200, 200, 100, "p8"), (2, 8, 100, 100, 0, "p8"),
+@pytest.mark.parametrize("B,H,Lq,Lk,split,mode", [(3, 16, 199, 199, 0, "p8"), (2, 8, 200, 200, 100, "p8"), (2, 8, 100, 100, 0, "p8"), (20, 16, 199, 199, 0, "p8"),
                                                   (3, 12, 100, 362, 0, "ar"), (2, 12, 97, 181, 0, "ar")])
 def test_attention_wide_kernel_is_bit_identical(tmp_path, B, H, Lq, Lk, split, mode):
     """attention_f16_wide_kernel / attention_f16_wide_ar_kernel (one workgroup per (clip, head), keys staged once / 192 at a time)
