@@ -21,7 +21,7 @@ SYMBOLS = [
     "artalk_create", "artalk_destroy", "artalk_last_error", "artalk_set_tensor", "artalk_finalize_weights",
     "artalk_reserve", "artalk_workspace_bytes", "artalk_weight_bytes", "artalk_infer", "artalk_get_status", "artalk_poll_status", "artalk_last_ticket", "artalk_get_status_of", "artalk_style_encode", "artalk_stream_begin", "artalk_stream_chunk", "artalk_stream_end", "artalk_savgol", "artalk_flame_create", "artalk_flame_verts", "artalk_flame_destroy", "artalk_flame_last_error",
     "artalk_set_profiling", "artalk_get_profile", "artalk_set_graphs", "artalk_set_overlap", "artalk_set_audit", "artalk_get_audit", "artalk_set_precision",
-    "artalk_op_gemm", "artalk_op_gemm_ex", "artalk_op_gemm_f16s", "artalk_op_pack_split", "artalk_op_gemm_f16s_packed", "artalk_op_mfma_f32_peak", "artalk_op_layernorm", "artalk_op_ar_skinny", "artalk_op_attention", "artalk_op_w2v_front", "artalk_op_resample_mean", "artalk_op_pool_silu",
+    "artalk_op_gemm", "artalk_op_gemm_ex", "artalk_op_gemm_f16s", "artalk_op_pack_split", "artalk_op_gemm_f16s_packed", "artalk_op_gemm_p8_plan", "artalk_op_mfma_f32_peak", "artalk_op_layernorm", "artalk_op_attention", "artalk_op_w2v_front", "artalk_op_resample_mean", "artalk_op_pool_silu",
     "artalk_op_bsq_history",
 ]
 
@@ -149,12 +149,12 @@ def lib() -> C.CDLL:
     L.artalk_op_pack_split.restype = i32
     L.artalk_op_gemm_f16s_packed.argtypes = [vp, i32, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.artalk_op_gemm_f16s_packed.restype = i32
+    L.artalk_op_gemm_p8_plan.argtypes = [i32, i32, i32]
+    L.artalk_op_gemm_p8_plan.restype = i32
     L.artalk_op_gemm_ex.argtypes = [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.artalk_op_gemm_ex.restype = i32
     L.artalk_op_mfma_f32_peak.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_double), vp]
     L.artalk_op_mfma_f32_peak.restype = i32
-    L.artalk_op_ar_skinny.argtypes = [vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
-    L.artalk_op_ar_skinny.restype = i32
     L.artalk_op_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]
     L.artalk_op_layernorm.restype = i32
     L.artalk_op_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, i32, vp]

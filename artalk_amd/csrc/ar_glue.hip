@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void style_finish_kernel(const float* __restri
     __shared__ float m[128];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int has = has_style ? has_style[b] : 0;
-    if (has == 0) {
+    if (has != 1 && has != 2) {      // 0 = no style; the host rejects other values (artalk_infer), anything else would read stale rows
         for (int e = tid; e < E; e += 256) style_cond[(long)b * E + e] = null_cond[e];
         return;
     }

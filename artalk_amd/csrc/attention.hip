@@ -1039,23 +1039,16 @@ void attention_prepare() {      // more than the default 64 KB of dynamic LDS fo
                               4 * 128 * 160);
     done[dev] = true;
 }
-static long wide_min_heads() {      // tuning: fewest (clip, head) pairs for which one workgroup per pair is taken
-    static const long v = getenv("ARTALK_ATTN_WIDE_MIN") ? atol(getenv("ARTALK_ATTN_WIDE_MIN")) : 1;
-    return v;
-}
 void launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.Lq <= 0) return;
-    static const int short_lq = getenv("ARTALK_ATTN_SHORT_LQ") ? atoi(getenv("ARTALK_ATTN_SHORT_LQ")) : 64;   // tuning
-    if (a.HD == 64 && a.split_q == 0 && a.Lq <= short_lq && a.Lk >= 64 && !a.qkv_p8) {
+    if (a.HD == 64 && a.split_q == 0 && a.Lq <= 64 && a.Lk >= 64 && !a.qkv_p8) {      // AR scale steps 0-3: key-split kernel
         hipLaunchKernelGGL(attention_short_kernel<64>, dim3((a.Lq + 15) / 16, a.H, a.B), dim3(256), 0, s, a);
         return;
     }
     dim3 grid((a.Lq + 63) / 64, a.H, a.B), block(256);
-    // v_exp_f32-based exp (1.2e-6 relative at |x| = 20, where p = 2e-9) by default: 154 -> 137 us per wav2vec2 layer; the fp32 kernels keep expf
-    static const int fastexp = getenv("ARTALK_ATTN_FASTEXP") ? atoi(getenv("ARTALK_ATTN_FASTEXP")) : 1;
-    static const int wide = getenv("ARTALK_ATTN_WIDE") ? atoi(getenv("ARTALK_ATTN_WIDE")) : 1;      // tuning: 0 = 64-query workgroups everywhere
-    if (a.HD == 64 && a.split16 && a.qkv_p8 && !a.l2norm && wide && a.Lq > 128 && a.Lq <= kWideMaxWaves * 16 && a.Lk <= kWideMaxKeys &&      // (100 queries: 7.2 vs 6.4 us, the two-workgroup form wins)
-        (long)a.B * a.H >= wide_min_heads()) {
+    // the f16 kernels use the v_exp_f32-based exp (1.2e-6 relative at |x| = 20, where p = 2e-9): 154 -> 137 us per wav2vec2 layer; the fp32 kernels keep expf
+    static const int wide = getenv("ARTALK_ATTN_WIDE") ? atoi(getenv("ARTALK_ATTN_WIDE")) : 1;      // 0 = 64-query workgroups everywhere (tests: the wide kernels are bit-identical to it)
+    if (a.HD == 64 && a.split16 && a.qkv_p8 && !a.l2norm && wide && a.Lq > 128 && a.Lq <= kWideMaxWaves * 16 && a.Lk <= kWideMaxKeys) {      // (100 queries: 7.2 vs 6.4 us, the two-workgroup form wins)
         const size_t lds = (size_t)4 * ((a.Lk + 31) & ~31) * 160;
         attention_prepare();
         // fewer (clip, head) pairs than CUs (the VAE stacks of one clip group: 128): two 7-wave workgroups per head, 128 keys per phase
@@ -1064,13 +1057,11 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((attention_f16_wide_kernel<1>), dim3(1, a.H, a.B), dim3(kWideMaxWaves * 64), lds, s, a);
     } else if (a.HD == 64 && a.split16 && a.qkv_p8 && !a.l2norm)
         hipLaunchKernelGGL((attention_f16_kernel<1, 1>), grid, block, 0, s, a);
-    else if (a.HD == 64 && a.split16 && fastexp && wide && !a.qkv_p8 && a.split_q == 0 && a.Lq > 32 && a.Lq <= kWideArWaves * 16 && a.Lk > 64) {
+    else if (a.HD == 64 && a.split16 && wide && !a.qkv_p8 && a.split_q == 0 && a.Lq > 32 && a.Lq <= kWideArWaves * 16 && a.Lk > 64) {
         attention_prepare();      // the 100-query scale step of the AR decoder: one workgroup per (clip, head), 192 keys per staging phase
         hipLaunchKernelGGL((attention_f16_wide_ar_kernel<1>), dim3(1, a.H, a.B), dim3(kWideArWaves * 64), (size_t)4 * kWideArKeys * 160, s, a);
-    } else if (a.HD == 64 && a.split16 && fastexp)
+    } else if (a.HD == 64 && a.split16)
         hipLaunchKernelGGL(attention_f16_kernel<1>, grid, block, 0, s, a);
-    else if (a.HD == 64 && a.split16)
-        hipLaunchKernelGGL(attention_f16_kernel<0>, grid, block, 0, s, a);
     else if (a.HD == 64)
         hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, a);
     else if (a.HD == 32)

@@ -110,11 +110,6 @@ struct artalk_model {
     unsigned int* audit_vals = nullptr;            // device, kAuditSlots floats (as bits)
     std::vector<std::string> audit_names;
     std::map<std::string, int> audit_index;
-    int posconv_lds = 1;              // tuning (ARTALK_POSCONV_LDS): LDS-resident positional convolution in f16x3 mode
-    int hist_kv_batched = 1;          // tuning (ARTALK_HIST_KV_BATCHED): history K/V of all blocks as one GEMM over column groups
-    int skinny_max_m = 0;             // experiment (ARTALK_SKINNY_MAX_M, 0 = off): AR scale steps of up to this many rows take the skinny kernels (ar_skinny.hip; measured: no gain)
-    int sm_big_cfg = 0, sm_big_min = 400;      // tuning (ARTALK_SM_BIG_CFG / _MIN): small-grid kernel configuration for unsplit grids of >= min tiles
-    int sm_split_768 = 1;             // tuning (ARTALK_SM_SPLIT768): split K = 768 GEMMs of the smallest scale steps too (deep-ring kernels)
     int stream_B = 0;                 // streams opened by artalk_stream_begin (history lives in the workspace)
     Workspace* view = nullptr;        // workspace view (clip sub-range) the body launchers currently work on; null = m->ws
     bool sticky_error = false;        // set by internal consistency checks inside the launch sequence; reported by artalk_infer
@@ -185,6 +180,14 @@ namespace {
     } while (0)
 
 int fail(artalk_model* m, int code, const std::string& msg) { m->err = msg; return code; }
+// the streaming / style-encode entry points run without stage events; the level comes back on every exit path
+struct ProfilingOff {
+    artalk_model* m; int saved;
+    explicit ProfilingOff(artalk_model* x) : m(x), saved(x->profiling) { m->profiling = 0; }
+    ~ProfilingOff() { m->profiling = saved; }
+    ProfilingOff(const ProfilingOff&) = delete;
+    ProfilingOff& operator=(const ProfilingOff&) = delete;
+};
 
 template <typename T>
 T* dalloc_in(std::vector<void*>& pool, int64_t n) {
@@ -438,7 +441,7 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
             if (g.K >= 2048) {
                 if (tiles <= 24) { S = 8; cfg = 23; }
                 else if (tiles < 192) S = tiles < 48 ? 6 : 3;
-            } else if (m->sm_split_768) {
+            } else {
                 if (tiles <= 24) { S = 6; cfg = 24; }
                 else if (tiles <= 36) { S = 4; cfg = 24; }
                 else if (tiles <= 72) { S = 3; cfg = 23; }
@@ -447,7 +450,6 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
             while (S > 1 && (int64_t)S * g.M * g.N > cw.splitk_floats) { --S; cfg = -1; }
             if (S == 5 || S == 7) { --S; }        // the unrolled reduce kernels exist for 2, 3, 4, 6, 8 slabs
             if (S > 1) { g.splitk = S; g.partial = cw.splitk; if (g.force_cfg < 0) g.force_cfg = cfg; }
-            else if (m->sm_big_cfg > 0 && tiles >= m->sm_big_min && g.force_cfg < 0) g.force_cfg = m->sm_big_cfg;
         } else if (tiles < lim) {
             int S = std::min(std::min(g.K / 64, (tgt + tiles - 1) / tiles), 16);
             while (S > 1 && (int64_t)S * g.M * g.N > cw.splitk_floats) --S;
@@ -551,7 +553,7 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
         GemmArgs g;
         g.A = w.h0; g.lda = Hs; g.W = m->pos_w; g.ldw = (long)cg * c.w2v_pos_kernel; g.bias = m->pos_b; g.C = w.h1; g.ldc = Hs; g.R = w.h0; g.ldr = Hs;
         g.M = M; g.act = ACT_GELU_ERF;
-        if (p8 && m->posconv_lds && cg == 64 && c.w2v_pos_kernel == 128 && c.w2v_pos_groups == 16 && m->Ts <= 256) {
+        if (p8 && cg == 64 && c.w2v_pos_kernel == 128 && c.w2v_pos_groups == 16 && m->Ts <= 256) {
             // f16x3 mode: one workgroup per (chunk, group) with the chunk's input window resident in LDS (posconv_p8_kernel)
             g.N = Hs; g.K = cg * c.w2v_pos_kernel; g.Wp = packed_of(m, m->pos_w); g.status = w.status;
             launch_posconv_p8(g, n, m->Tw, m->Ts, s);
@@ -702,7 +704,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
         g.M = B * kNTok; g.N = c.ar_depth * 2 * kE; g.K = kE;
         g.ngrp = 2 * kE; g.grpW = (long)3 * kE * kE; g.grpB = 3 * kE; g.grpC = cache_l;
         g.Wp = packed_of(m, g.W);
-        if (p8 && m->hist_kv_batched && gemm_p8_eligible(g)) {
+        if (p8 && gemm_p8_eligible(g)) {
             gemm(m, g, s);
         } else {
             for (int l = 0; l < c.ar_depth; ++l) {          // exact-f32 mode / small batches: one launch per block
@@ -738,46 +740,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
             return n;
         };
         bool have_ln = false;                                  // w.xmod already holds the norm the next GEMM reads
-        // experiment, off by default: four skinny launches per block on the smallest scale steps (LayerNorms fused into q|k|v and
-        // FFN-in, no split-K passes).  113 -> 65 launches per 1-token step, but a 16-column sliver engages only N / 16 CUs: 9-10 us
-        // per LayerNorm-fused launch, 15 us for FFN-out against 17 for the split GEMM + fused reduce/LayerNorm - 0.1 ms of a 35 ms
-        // body at 16 rows, slower at 80.  The headroom audit reads the LayerNorm outputs, so it keeps the tiled path.
-        const bool skinny = p8 && M <= m->skinny_max_m && !m->audit;
-        for (int l = 0; skinny && l < c.ar_depth; ++l) {
-            const ARLayer& L = m->ar[l];
-            const float* ada = w.ada + (long)l * 6 * kE;
-            float* cache = w.cache + l * cache_l;
-            const LnArgs n1 = ln_args(l, 0), n2 = ln_args(l, 1);
-            GemmArgs q;
-            q.W = L.qkv_w; q.Wp = packed_of(m, L.qkv_w); q.ldw = kE; q.bias = L.qkv_b; q.C = cache; q.ldc = 3 * kE;
-            q.cmap = rowmap(pn, 2 * kNTok, kNTok + off); q.M = M; q.N = 3 * kE; q.K = kE; q.status = w.status;
-            GemmArgs pj;
-            pj.A = w.attn_out; pj.lda = kE; pj.a_packed = 1; pj.W = L.proj_w; pj.Wp = packed_of(m, L.proj_w); pj.ldw = kE; pj.bias = L.proj_b;
-            pj.C = w.x; pj.ldc = kE; pj.gate = ada; pj.ldg = ldada; pj.gmap = amap; pj.R = w.x; pj.ldr = kE; pj.M = M; pj.N = kE; pj.K = kE;
-            pj.status = w.status;
-            GemmArgs f1;
-            f1.W = L.ffn1_w; f1.Wp = packed_of(m, L.ffn1_w); f1.ldw = kE; f1.bias = L.ffn1_b; f1.C = w.ffn_h; f1.ldc = 4 * kE; f1.c_p8 = 1;
-            f1.act = ACT_GELU_TANH; f1.M = M; f1.N = 4 * kE; f1.K = kE; f1.status = w.status;
-            GemmArgs f2;
-            f2.A = w.ffn_h; f2.lda = 4 * kE; f2.a_packed = 1; f2.W = L.ffn2_w; f2.Wp = packed_of(m, L.ffn2_w); f2.ldw = 4 * kE; f2.bias = L.ffn2_b;
-            f2.C = w.x; f2.ldc = kE; f2.gate = ada + kE; f2.ldg = ldada; f2.gmap = amap; f2.R = w.x; f2.ldr = kE; f2.M = M; f2.N = kE; f2.K = 4 * kE;
-            f2.status = w.status;
-            if (l == 0 && !(ar_skinny_eligible(q, &n1) && ar_skinny_eligible(pj, nullptr) && ar_skinny_eligible(f1, &n2) && ar_skinny_eligible(f2, nullptr))) {
-                m->err = "internal: skinny AR kernels not applicable"; m->sticky_error = true; return;
-            }
-            launch_ar_skinny(q, &n1, s);
-            AttnArgs a;
-            a.Q = cache + (long)(kNTok + off) * 3 * kE; a.K = cache + kE; a.V = cache + 2 * kE;
-            a.ldq = a.ldk = a.ldv = 3 * kE; a.q_bstride = a.k_bstride = a.v_bstride = (long)2 * kNTok * 3 * kE;
-            a.O = w.attn_out; a.ldo = kE; a.o_bstride = (long)pn * kE;
-            a.B = B; a.H = c.ar_heads; a.HD = kE / c.ar_heads; a.Lq = pn; a.Lk = kNTok + off + pn; a.scale = 1.0f;
-            a.l2norm = 1; a.qscale = L.qscale; a.out_p8 = p8; a.split16 = p8; a.status = w.status;
-            launch_attention(a, s);
-            launch_ar_skinny(pj, nullptr, s);
-            launch_ar_skinny(f1, &n2, s);
-            launch_ar_skinny(f2, nullptr, s);
-        }
-        for (int l = 0; !skinny && l < c.ar_depth; ++l) {
+        for (int l = 0; l < c.ar_depth; ++l) {
             const ARLayer& L = m->ar[l];
             const float* ada = w.ada + (long)l * 6 * kE;
             float* cache = w.cache + l * cache_l;
@@ -1047,12 +1010,6 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return ARTALK_EHIP; }
     artalk_model* m = new artalk_model();
     m->cfg = c; m->device = device_id;
-    if (const char* e = getenv("ARTALK_SM_SPLIT768")) m->sm_split_768 = atoi(e);
-    if (const char* e = getenv("ARTALK_SKINNY_MAX_M")) m->skinny_max_m = atoi(e);
-    if (const char* e = getenv("ARTALK_SM_BIG_CFG")) m->sm_big_cfg = atoi(e);
-    if (const char* e = getenv("ARTALK_SM_BIG_MIN")) m->sm_big_min = atoi(e);
-    if (const char* e = getenv("ARTALK_HIST_KV_BATCHED")) m->hist_kv_batched = atoi(e);
-    if (const char* e = getenv("ARTALK_POSCONV_LDS")) m->posconv_lds = atoi(e);
     // conv stack geometry: T_l valid frames; row stride S_l per chunk with S_l = 2*S_{l+1} so that one GEMM covers all chunks
     int T = kSamplesPerChunk;
     for (int i = 0; i < c.w2v_n_conv; ++i) { T = (T - c.w2v_conv_kernel[i]) / c.w2v_conv_stride[i] + 1; m->conv_T[i] = T; }
@@ -1312,6 +1269,13 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
         if (n_chunks[b] <= 0 || (b > 0 && n_chunks[b] > n_chunks[b - 1])) return fail(m, ARTALK_EINVAL, "n_chunks must be positive and non-increasing");
         C += n_chunks[b];
     }
+    bool encode_style = false;      // validated before anything is enqueued or any state changes
+    if (style_motion_dev && has_style) {
+        for (int b = 0; b < B; ++b) {
+            if (has_style[b] > 2) return fail(m, ARTALK_EINVAL, "has_style entries must be 0, 1 or 2");
+            encode_style |= has_style[b] == 1;
+        }
+    }
     if (B > m->ws.maxB || C > m->ws.maxC) { if (int rc = reserve(m, B, (int)C)) return rc; }
     Workspace& w = m->ws;
     // chunk list, chunk-index major: chunk (j, b) for all b with n_chunks[b] > j  -> active clips are a prefix
@@ -1368,13 +1332,6 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
         m->view = nullptr;
     }
     stage_mark(m, s, PB_OTHER);
-    bool encode_style = false;
-    if (style_motion_dev && has_style) {
-        for (int b = 0; b < B; ++b) {
-            if (has_style[b] > 2) return fail(m, ARTALK_EINVAL, "has_style entries must be 0, 1 or 2");
-            encode_style |= has_style[b] == 1;
-        }
-    }
     run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s, encode_style);
     stage_mark(m, s, PB_STYLE);
     if (!overlap) {
@@ -1437,9 +1394,10 @@ int artalk_style_encode(artalk_model* m, const float* style_motion_dev, int n, f
     if (n > m->ws.maxB) { if (int rc = reserve(m, n, std::max(n, m->ws.maxC))) return rc; }
     Workspace& w = m->ws;
     HIPCHK(m, hipMemsetAsync(w.has_style, 1, n, s));
-    const int saved = m->profiling; m->profiling = 0;
-    run_style(m, style_motion_dev, n, s, true);
-    m->profiling = saved;
+    {
+        ProfilingOff quiet(m);
+        run_style(m, style_motion_dev, n, s, true);
+    }
     HIPCHK(m, hipMemcpyAsync(out_cond_dev, w.style_cond, (size_t)n * kE * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(m, hipGetLastError());
     return ARTALK_OK;
@@ -1451,6 +1409,12 @@ int artalk_style_encode(artalk_model* m, const float* style_motion_dev, int n, f
 int artalk_stream_begin(artalk_model* m, int B, const float* style_motion_dev, const uint8_t* has_style, void* stream) {
     if (!m || B <= 0) return ARTALK_EINVAL;
     if (!m->finalized) return fail(m, ARTALK_ESTATE, "artalk_stream_begin before artalk_finalize_weights");
+    bool encode_style = false;
+    if (style_motion_dev && has_style)
+        for (int b = 0; b < B; ++b) {
+            if (has_style[b] > 2) return fail(m, ARTALK_EINVAL, "has_style entries must be 0, 1 or 2");
+            encode_style |= has_style[b] == 1;
+        }
     (void)hipSetDevice(m->device);
     if (!stream && !m->own_stream) HIPCHK(m, hipStreamCreate(&m->own_stream));
     hipStream_t s = stream ? (hipStream_t)stream : m->own_stream;
@@ -1466,14 +1430,12 @@ int artalk_stream_begin(artalk_model* m, int B, const float* style_motion_dev, c
         stg->used = true;
     }
     HIPCHK(m, hipMemsetAsync(w.status, 0, 4 * sizeof(int), s));   // the status word covers the whole streaming session
-    const int saved = m->profiling; m->profiling = 0;
-    bool encode_style = false;
-    if (style_motion_dev && has_style)
-        for (int b = 0; b < B; ++b) encode_style |= has_style[b] == 1;
-    run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s, encode_style);
-    launch_enc_input_zero(m->vae_mean, m->vae_std, m->enc_pos, w.enc_in, B, s);
-    run_reencode(m, B, s);
-    m->profiling = saved;
+    {
+        ProfilingOff quiet(m);
+        run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s, encode_style);
+        launch_enc_input_zero(m->vae_mean, m->vae_std, m->enc_pos, w.enc_in, B, s);
+        run_reencode(m, B, s);
+    }
     m->stream_B = B;
     if (int rc = publish_status(m, s)) return rc;
     HIPCHK(m, hipGetLastError());
@@ -1498,7 +1460,7 @@ int artalk_stream_chunk(artalk_model* m, const float* audio_dev, int64_t chunk_s
     HIPCHK(m, hipMemcpyAsync(w.src_off, stg->src, B * sizeof(long), hipMemcpyHostToDevice, s));
     HIPCHK(m, hipEventRecord(stg->done, s));
     stg->used = true;
-    const int saved = m->profiling; m->profiling = 0;
+    ProfilingOff quiet(m);      // restored on every exit path
     for (int c0 = 0; c0 < B; c0 += w.G) run_wav2vec(m, audio_dev, c0, std::min(w.G, B - c0), nullptr, s);
     linear(m, w.silu_cond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, B * kNTok, m->ada_n, kCond, ACT_NONE, nullptr, s,
            m->precision == 1 ? LF_A_P8 : 0);
@@ -1507,7 +1469,6 @@ int artalk_stream_chunk(artalk_model* m, const float* audio_dev, int64_t chunk_s
     } else {
         if (int brc = run_chunk_body_split(m, B, s)) return brc;
     }
-    m->profiling = saved;
     const size_t mrow = (size_t)100 * m->cfg.motion_dim * 4;
     HIPCHK(m, hipMemcpy2DAsync(out_motion_dev, (size_t)out_stride * 4, w.motion_chunk, mrow, mrow, B, hipMemcpyDeviceToDevice, s));
     if (int rc = publish_status(m, s)) return rc;
@@ -1652,11 +1613,11 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
     g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act & 0xff; g.force_cfg = force_cfg;
     g.c_p8 = (act >> 8) & 1;      // tuning: bit 8 of `act` = result in the P8 split format (same pitch)
     if ((act >> 9) & 1) { g.R = C; g.ldr = N; }      // tuning: bit 9 = residual read from C (in place, as the encoder's out-projection / FFN-out run)
-    if (force_cfg >= 2) {   // LDS-DMA pipelined kernel (needs both operands in P8); 3 / 5 select the pipeline depth, 6 = 256x128 tiles, 2 = default
+    if (force_cfg >= 2) {   // LDS-DMA kernels (both operands in P8): 7 = 256x256 tiles, 8 = persistent 128x128, 17 = 7 with wall-clock stamps
         if (!a_packed) return ARTALK_EINVAL;
         g.force_cfg = force_cfg == 99 ? -1 : force_cfg;   // 99: the engine's own choice between the production kernels
-        if (force_cfg >= 16 && force_cfg <= 18) { g.partial = (float*)bias; g.bias = nullptr; }   // timing build: `bias` carries the stamp buffer (8 x u64 per tile)
-        if ((force_cfg & 0xff) >= 20 || ((force_cfg & 0xff) == 8 && (force_cfg >> 8))) {     // 20-22: small-grid LDS-DMA kernel, 8: two-workgroup kernel; bits 8-15: split-K factor (slabs in a temporary)
+        if (force_cfg == 17) { g.partial = (float*)bias; g.bias = nullptr; }   // timing build: `bias` carries the stamp buffer (8 x u64 per tile)
+        if (force_cfg != 99 && (force_cfg & 0xff) >= 20) {     // 20 / 23 / 24: small-grid LDS-DMA kernel; bits 8-15: split-K factor (slabs in a temporary)
             g.force_cfg = force_cfg & 0xff;
             const int S = (force_cfg >> 8) & 0xff;
             static float* part = nullptr;       // tuning/test scratch, grown on demand and kept (never used by the model path)
@@ -1672,7 +1633,7 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
                 }
                 g.splitk = S; g.partial = part;
             }
-            if (g.force_cfg == 8) launch_gemm_p8(g, (hipStream_t)stream); else launch_gemm_p8_sm(g, (hipStream_t)stream);
+            launch_gemm_p8_sm(g, (hipStream_t)stream);
             if (S > 1) launch_splitk_reduce(g, (hipStream_t)stream);
         } else {
             launch_gemm_p8(g, (hipStream_t)stream);
@@ -1683,19 +1644,10 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }
 
-int artalk_op_ar_skinny(const void* A_p8, const float* X, const float* scale, const float* shift, float eps, const void* Wp, const float* bias,
-                        const float* gate, const float* R, float* C, int M, int N, int K, int act, void* stream) {
-    if (!Wp || !C || (!A_p8 && !X) || M <= 0) return ARTALK_EINVAL;
+int artalk_op_gemm_p8_plan(int M, int N, int K) {
     GemmArgs g;
-    g.A = (const float*)A_p8; g.lda = K; g.a_packed = A_p8 ? 1 : 0; g.Wp = (const unsigned int*)Wp; g.ldw = K; g.bias = bias;
-    g.C = C; g.ldc = N; g.gate = gate; g.ldg = N; g.R = R; g.ldr = N; g.M = M; g.N = N; g.K = K;
-    g.act = act & 0xff; g.c_p8 = (act >> 8) & 1;      // act | 0x100: result in the P8 split format
-    LnArgs ln;
-    ln.X = X; ln.ldx = K; ln.scale = scale; ln.shift = shift; ln.ldm = K; ln.M = M; ln.D = K; ln.eps = eps;
-    const LnArgs* lp = X ? &ln : nullptr;
-    if (!ar_skinny_eligible(g, lp)) return ARTALK_EINVAL;
-    launch_ar_skinny(g, lp, (hipStream_t)stream);
-    return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
+    g.M = M; g.N = N; g.K = K;
+    return gemm_p8_variant(g) == 1 ? 7 : 8;
 }
 
 int artalk_op_layernorm(const float* X, float* Y, const float* w, const float* b, const float* scale, const float* shift, int M,

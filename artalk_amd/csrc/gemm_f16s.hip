@@ -216,12 +216,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// LDS-DMA pipeline variant for the large GEMMs: BOTH operands already in P8 (A written in P8 by its producer kernel), so
-// staging is a pure byte copy and goes global -> LDS directly (global_load_lds_dwordx4: no staging registers), STAGES-1
-// K tiles in flight behind counted vmcnt waits and ONE raw s_barrier per K step.  The register-staged kernel above has a
-// single K tile of prefetch and is load-latency bound; here 3 tiles (96 KiB) stay in flight per CU.
-//   tile 128x128, BK = 32, 8 waves (2 x 4, each 64 x 32: 2 m-tiles x 1 n-tile, main + cross accumulators = 64 regs)
-//   LDS stage: A 128 rows x 128 B, then W 128 rows x 128 B, rows unpadded (a DMA wave-instruction writes 1 KiB = 8 rows);
+// LDS-DMA kernels: BOTH operands already in P8 (A written in P8 by its producer kernel), so staging is a pure byte copy and goes
+// global -> LDS directly (global_load_lds_dwordx4: no staging registers) behind counted vmcnt waits and ONE raw s_barrier per K step.
+//   LDS stage: A rows x 128 B, then W rows x 128 B (BK = 32), rows unpadded (a DMA wave-instruction writes 1 KiB = 8 rows);
 //   16-byte chunk c of row r lives at physical chunk c ^ ((r >> 1) & 7): the XOR is applied to the per-lane SOURCE address
 //   of the DMA and again on the fragment read (same involution), which makes the ds_read_b128 fragment reads conflict-free.
 template <int N>
@@ -253,226 +250,9 @@ __device__ __forceinline__ void wait_vmcnt_units(int units) {   // at most `unit
     else wait_vmcnt<0>();
 }
 
-// BM = 128: waves 2 x 4, wave tile 64 x 32, 4 stages of 32 KiB.  BM = 256: waves 4 x 2, wave tile 64 x 64, 3 stages of 48 KiB
-// (3/4 of the operand bytes per flop).
-// ABL == 6 (tools/gemm_p8_stamps.py): the same kernel + wall-clock stamps (100 MHz) per workgroup in g.partial as 8 x u64:
-// entry, first stage landed, main loop done, epilogue done, HW_ID, XCC_ID.
-template <int BM, int STAGES, int ABL = 0>
-__global__ __launch_bounds__(512, 1) void gemm_p8_kernel(const GemmArgs g) {
-    constexpr int BN = 128, BK = 32;
-    constexpr int WN_WAVES = (BM == 128) ? 4 : 2;          // waves along N
-    constexpr int TN = BN / WN_WAVES / 32;                 // n-tiles per wave (1 or 2); m-tiles per wave = 2
-    constexpr int APIECES = BM / 64, WPIECES = 2;          // 1-KiB DMA pieces per wave per stage
-    constexpr int NDMA = APIECES + WPIECES;
-    constexpr int STAGE_BYTES = (BM + BN) * 128;
-    static_assert(STAGES * STAGE_BYTES <= 160 * 1024, "LDS");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
-
-    const int tid = threadIdx.x;
-    unsigned long long* stamps = nullptr;
-    if constexpr (ABL == 6) {
-        stamps = reinterpret_cast<unsigned long long*>(g.partial) + (long)blockIdx.x * 8;
-        if (tid == 0) {
-            stamps[0] = wall_clock64();
-            stamps[4] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID, all 32 bits
-            stamps[5] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
-        }
-    }
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
-    int tm, tn;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        constexpr int GM = (BM == 128) ? 4 : 2;
-        const int width = GM * tiles_n;
-        const int group = idx / width, first_m = group * GM;
-        const int gsz = min(tiles_m - first_m, GM);
-        const int in_g = idx - group * width;
-        tn = in_g / gsz;
-        tm = first_m + (in_g - tn * gsz);
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // ---- DMA addressing: 1-KiB pieces (8 rows x 128 B); lane = (row in piece, physical chunk) ----
-    const int prow = lane >> 3, pchunk = lane & 7;
-    const unsigned char* asrc[APIECES];
-    const unsigned char* wsrc[WPIECES];
-#pragma unroll
-    for (int q = 0; q < APIECES; ++q) {
-        const int ra = (wave * APIECES + q) * 8 + prow;                 // tile row 0..BM-1
-        const int gm = min(m0 + ra, g.M - 1);                           // clamp: rows >= M are never stored
-        asrc[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda) * 4 + ((pchunk ^ ((ra >> 1) & 7)) << 4);
-    }
-#pragma unroll
-    for (int q = 0; q < WPIECES; ++q) {
-        const int rw = (wave * WPIECES + q) * 8 + prow;
-        const int gn = min(n0 + rw, g.N - 1);
-        wsrc[q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw) * 4 + ((pchunk ^ ((rw >> 1) & 7)) << 4);
-    }
-    // piece q of this wave for K tile kt into ring buffer buf: q < APIECES -> A rows, else W rows
-    auto issue_piece = [&](int q, int kt, int buf) {
-        unsigned char* base = smem_p8 + buf * STAGE_BYTES;
-        const long koff = (long)kt * (BK * 4);
-        if (q < APIECES)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[q] + koff),
-                                             (__attribute__((address_space(3))) void*)(base + (wave * APIECES + q) * 1024), 16, 0, 0);
-        else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q - APIECES] + koff),
-                                             (__attribute__((address_space(3))) void*)(base + BM * 128 + (wave * WPIECES + q - APIECES) * 1024), 16, 0, 0);
-    };
-    auto issue = [&](int kt, int buf) {
-#pragma unroll
-        for (int q = 0; q < NDMA; ++q) issue_piece(q, kt, buf);
-    };
-
-    const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
-    const int r = lane & 31, h = lane >> 5;
-    // LDS byte addresses of this lane's fragments inside a stage, [kb][hi/lo]; the second m tile (and n tile) is 32 rows = 4096 B
-    // further on with the same swizzle key, which goes into the instruction's immediate offset
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_p8;
-    unsigned a_off[2][2], w_off[2][2];
-    {
-        const int arow = wm * 64 + r, wrow = wn * (32 * TN) + r;
-        const int akey = (arow >> 1) & 7, wkey = (wrow >> 1) & 7;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int lo = 0; lo < 2; ++lo) {
-                const int c = (kb * 2 + h) * 2 + lo;     // logical 16-byte chunk: hi fragment, lo = the next one
-                a_off[kb][lo] = lds0 + arow * 128 + ((c ^ akey) << 4);
-                w_off[kb][lo] = lds0 + BM * 128 + wrow * 128 + ((c ^ wkey) << 4);
-            }
-    }
-
-    f32x16 acc[2][TN];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nk = g.K / BK;
-#pragma unroll
-    for (int st = 0; st < STAGES - 1; ++st)
-        if (st < nk) issue(st, st);
-
-    // Fragment registers are one half-step ahead of the MFMAs, so LDS-read latency and the stage hand-over (vmcnt wait +
-    // barrier) sit under matrix work instead of in front of it.  Steady-state iteration kt (branch-free, so that hipcc counts
-    // its lgkmcnt waits exactly instead of draining at a join):
-    //   read kb=1 frags of stage kt | 6 MFMA kb=0 | vmcnt: stage kt+1 landed | barrier |
-    //   read kb=0 frags of stage kt+1 | 6 MFMA kb=1 with the DMA pieces of stage kt+S-1 issued one per MFMA gap
-    // The DMA reuses the buffer of stage kt-1, whose fragment reads were all consumed by MFMAs issued before this barrier, so no
-    // lgkmcnt drain is needed in front of the barrier and the kb=1 reads of stage kt stay in flight across it.
-    constexpr int NRD = 4 + 2 * TN;    // ds_read_b128 per half step
-    auto read_frags = [&](int buf, int kb, f16x8 (&ah)[2], f16x8 (&al)[2], f16x8 (&bh)[TN], f16x8 (&bl)[TN]) {
-        const unsigned sb = buf * STAGE_BYTES;
-        const unsigned ahp = a_off[kb][0] + sb, alp = a_off[kb][1] + sb, whp = w_off[kb][0] + sb, wlp = w_off[kb][1] + sb;
-        bh[0] = lds_read128<0>(whp);
-        ah[0] = lds_read128<0>(ahp);
-        bl[0] = lds_read128<0>(wlp);
-        al[0] = lds_read128<0>(alp);
-        ah[1] = lds_read128<4096>(ahp);
-        al[1] = lds_read128<4096>(alp);
-        if constexpr (TN == 2) {
-            bh[TN - 1] = lds_read128<4096>(whp);
-            bl[TN - 1] = lds_read128<4096>(wlp);
-        }
-    };
-    constexpr int NMF = 2 * TN * 3;    // MFMAs per half step
-    auto mfma_slot = [&](int sidx, const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
-        // term-major order: consecutive MFMAs go to different accumulators.  Weight fragment = A operand: C^T, see epilogue_tile32
-        const int t = sidx / (2 * TN), i = (sidx / TN) % 2, j = sidx % TN;
-        if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-        else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
-    };
-    auto mfmas = [&](const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
-#pragma unroll
-        for (int sidx = 0; sidx < NMF; ++sidx) mfma_slot(sidx, ah, al, bh, bl);
-    };
-
-    f16x8 ah0[2], al0[2], bh0[TN], bl0[TN], ah1[2], al1[2], bh1[TN], bl1[TN];
-    wait_vmcnt_units<NDMA>(min(STAGES - 2, nk - 1));   // stage 0 landed (the prologue left up to STAGES-2 younger stages in flight)
-    __builtin_amdgcn_s_barrier();
-    if constexpr (ABL == 6) { if (tid == 0) stamps[1] = wall_clock64(); }
-    read_frags(0, 0, ah0, al0, bh0, bl0);
-    int kt = 0, buf = 0;                               // buf = kt % STAGES
-    for (; kt + STAGES - 1 < nk; ++kt) {               // steady state: stage kt+S-1 still to be fetched
-        const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
-        const int fbuf = (buf == 0) ? STAGES - 1 : buf - 1;     // (kt + S - 1) % S
-        read_frags(buf, 1, ah1, al1, bh1, bl1);
-        wait_lgkmcnt<NRD>();                           // the kb=0 fragments (issued half a step ago) are in; the kb=1 reads fly on
-        mfmas(ah0, al0, bh0, bl0);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_vmcnt<(STAGES - 3) * NDMA>();             // stage kt+1 landed for this wave (stages kt+2 .. kt+S-2 may still fly)
-        __builtin_amdgcn_s_barrier();                  // ... and for every wave; every wave is done with stage kt-1
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(nbuf, 0, ah0, al0, bh0, bl0);
-        wait_lgkmcnt<NRD>();                           // kb=1 fragments of stage kt
-#pragma unroll
-        for (int sidx = 0; sidx < NMF; ++sidx) {
-            mfma_slot(sidx, ah1, al1, bh1, bl1);
-            if (sidx < NDMA) {
-                __builtin_amdgcn_sched_barrier(0);
-                issue_piece(sidx, kt + STAGES - 1, fbuf);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        buf = nbuf;
-    }
-    for (; kt < nk; ++kt) {                            // drain: the last S-1 stages are in flight or landed
-        const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
-        read_frags(buf, 1, ah1, al1, bh1, bl1);
-        wait_lgkmcnt<NRD>();
-        mfmas(ah0, al0, bh0, bl0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
-            wait_vmcnt_units<NDMA>(min(STAGES - 3, nk - 2 - kt));
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            read_frags(nbuf, 0, ah0, al0, bh0, bl0);
-            wait_lgkmcnt<NRD>();
-        } else {
-            wait_lgkmcnt<0>();
-        }
-        mfmas(ah1, al1, bh1, bl1);
-        __builtin_amdgcn_sched_barrier(0);
-        buf = nbuf;
-    }
-    if constexpr (ABL == 6) { if (tid == 0) stamps[2] = wall_clock64(); }
-
-    const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
-    if (epi.vec) {      // coalesced: transpose through this wave's slice of the (now idle) stage ring
-        __builtin_amdgcn_s_barrier();      // every wave has consumed its last fragments
-        constexpr int SLICE = 64 * (32 * TN + 4);
-        static_assert(8 * SLICE * 4 <= STAGES * STAGE_BYTES, "epilogue LDS");
-        epilogue_wave_lds<2, TN>(g, epi, reinterpret_cast<float*>(smem_p8) + wave * SLICE, m0 + wm * 64, n0 + wn * (32 * TN), lane, acc);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) epilogue_tile32<true, false>(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * (32 * TN) + j * 32, h, acc[i][j]);
-    }
-    if constexpr (ABL == 6) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (tid == 0) stamps[3] = wall_clock64();
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
-// 256x256 tile variant of the LDS-DMA kernel.  The 128x128 kernel above is bound by what the LDS-DMA path of a CU delivers
-// (~60 GB/s: 32 KiB per K step in 0.53 us with the MFMAs removed, 0.68 us with them); a 256x256 tile needs half the operand
+// 256x256 tile variant of the LDS-DMA kernel.  A 128x128 tile is bound by what the LDS-DMA path of a CU delivers
+// (~60 GB/s: 32 KiB per K step in 0.53 us with the MFMAs removed); a 256x256 tile needs half the operand
 // bytes per flop, which one fp32 accumulator per output (common.h: both operand halves share a scale) makes affordable:
 // 8 waves as 2 x 4, wave tile 128 x 64 = 4 x 2 MFMA tiles = 128 accumulator registers.
 //   LDS: 2 stages of 64 KiB (A 256 rows x 128 B, then W 256 rows x 128 B, same XOR swizzle as above).  One K step (32 deep)
@@ -507,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        const int GM = g.tile_gm > 0 ? g.tile_gm : 8;      // row tiles per XCD tile group (tuning: ARTALK_P8_256_GM; 8 x 4 tiles per XCD measured 0.27 ms per step better than 2 x 16)
+        constexpr int GM = 8;      // row tiles per XCD tile group (8 x 4 tiles per XCD measured 0.27 ms per step better than 2 x 16)
         const int width = GM * tiles_n;
         const int group = idx / width, first_m = group * GM;
         const int gsz = min(tiles_m - first_m, GM);
@@ -660,13 +440,257 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// Persistent big-tile kernel: (64 TM) x 256 tiles, TM = 4 (256 x 256, the tile of gemm_p8_256_kernel) or 5 (320 x 256), one
+// workgroup of 8 waves (2 x 4, wave tile 32 TM x 64 = TM x 2 MFMA tiles = 128 / 160 accumulator registers) per CU walking the
+// tile list with stride gridDim.x.  What it adds to gemm_p8_256_kernel:
+//   * the LDS-DMA ring runs ACROSS tile boundaries: stage 0 of the next tile is fetched during the last K step of this one and its
+//     stage 1 right after that step's barrier, so a tile has no prologue (3.3 us of 90) and the DMA latency of the first two stages
+//     sits under the epilogue;
+//   * the epilogue stores straight from the accumulators (no LDS transposition: the ring is busy) and the next tile starts behind
+//     counted vmcnt waits that leave those stores in flight for its first two K steps;
+//   * the bias row of a tile arrives by one more DMA instruction per wave with its stage 0 (256 B per wave, two slots) and is read with
+//     ds_read in the epilogue: no vector-memory LOAD sits between the stores (vmcnt counts loads and stores in issue order, a load
+//     in the epilogue would drain every store in front of it);
+//   * 320 x 256 tiles: the M = 19200 GEMMs of batch 32 cut into 60 row tiles, so N = 1024 (out-projection, FFN-out) is ONE round of
+//     240 workgroups on 256 CUs instead of 2.34 rounds of the 128x128 kernel's 512, and q|k|v 2.81 rounds instead of 3.52.
+// Accumulation order per output element is that of every other split kernel (k ascending; hi*hi, lo*hi, hi*lo per 16-deep block), so
+// results are bit-identical to theirs.
+template <int U, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (U < N) {
+        f(std::integral_constant<int, U>{});
+        static_for<U + 1, N>(f);
+    }
+}
+template <int TM, int TAG = 0>
+__global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 256, BK = 32;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int NDMA = TM + 4;                      // 1-KiB pieces per wave per stage: TM of A, 4 of W
+    constexpr int NSUB = 2 * TM;                      // sub-steps (k block, m tile) of a K step
+    constexpr int BIAS_OFF = 2 * STAGE_BYTES;         // two slots of 8 x 256 B behind the ring
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    const int ntiles = tiles_n * tiles_m;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const int nk = g.K / BK;
+
+    // tile index -> origin: XCD-contiguous (workgroups b and b + 8 share an XCD and gridDim.x % 8 == 0, so tile t runs on XCD t & 7),
+    // grouped column-major inside groups of 8 row tiles (8 x 4 tiles per XCD at a time)
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        const int xcd = t & 7, q = ntiles >> 3, rr = ntiles & 7;
+        const int idx = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
+        constexpr int GM = 8;
+        const int width = GM * tiles_n;
+        const int group = idx / width, first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        const int in_g = idx - group * width;
+        const int tn = in_g / gsz;
+        m0 = (first_m + (in_g - tn * gsz)) * BM;
+        n0 = tn * BN;
+    };
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_p8;
+    unsigned a_off[2][2], w_off[2][2];               // [kb][hi/lo]; further tiles are +4096 B per 32 rows (same swizzle key)
+    {
+        const int arow = wm * (32 * TM) + r, wrow = wn * 64 + r;
+        const int akey = (arow >> 1) & 7, wkey = (wrow >> 1) & 7;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int lo = 0; lo < 2; ++lo) {
+                const int c = (kb * 2 + h) * 2 + lo;
+                a_off[kb][lo] = lds0 + arow * 128 + ((c ^ akey) << 4);
+                w_off[kb][lo] = lds0 + BM * 128 + wrow * 128 + ((c ^ wkey) << 4);
+            }
+    }
+
+    const unsigned char* src[NDMA];
+    const float* bias_src = nullptr;
+    auto set_src = [&](int m0, int n0) {
+#pragma unroll
+        for (int q = 0; q < TM; ++q) {
+            const int ra = (wave * TM + q) * 8 + prow;                  // tile row of this lane in piece q
+            const int gm = min(m0 + ra, g.M - 1);                       // clamp: rows >= M are never stored
+            src[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda) * 4 + ((pchunk ^ ((ra >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rw = (wave * 4 + q) * 8 + prow;
+            const int gn = min(n0 + rw, g.N - 1);
+            src[TM + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw) * 4 + ((pchunk ^ ((rw >> 1) & 7)) << 4);
+        }
+        // this wave's 64 bias values, one float per lane (an address that is always valid when there is no bias: the slot is then unused)
+        bias_src = g.bias ? g.bias + min(n0 + wn * 64 + lane, g.N - 1) : reinterpret_cast<const float*>(g.Wp) + lane;
+    };
+    auto issue_piece = [&](int q, int kt, int buf) {
+        unsigned char* dst = smem_p8 + buf * STAGE_BYTES + (q < TM ? (wave * TM + q) * 1024 : BM * 128 + (wave * 4 + q - TM) * 1024);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (long)kt * (BK * 4)),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    auto issue_bias = [&](int slot) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bias_src,
+                                         (__attribute__((address_space(3))) void*)(smem_p8 + BIAS_OFF + slot * 2048 + wave * 256), 4, 0, 0);
+    };
+
+    f32x16 acc[TM][2];
+    f16x8 bh[2][2], bl[2][2];      // [k block][n tile]
+    f16x8 ah[2], al[2];            // two slots, sub-step u lives in slot u & 1
+    auto read_b = [&](unsigned sb, int kb) {
+        bh[kb][0] = lds_read128<0>(w_off[kb][0] + sb);
+        bl[kb][0] = lds_read128<0>(w_off[kb][1] + sb);
+        bh[kb][1] = lds_read128<4096>(w_off[kb][0] + sb);
+        bl[kb][1] = lds_read128<4096>(w_off[kb][1] + sb);
+    };
+    // One K step out of ring buffer `buf`.  ISSUE: the pieces of K tile kt_issue of the tile `src` points at go into the other buffer
+    // meanwhile, one per two MFMAs.  pre: vector-memory instructions that may stay in flight at the top (everything OLDER than them
+    // - in particular this step's stage - has landed).
+    auto kstep = [&](int buf, auto issue_tag, int kt_issue, int pre) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        const unsigned sb = buf * STAGE_BYTES;
+        if (pre <= 0) wait_vmcnt<0>();
+        else if (pre == NDMA) wait_vmcnt<NDMA>();
+        else if (pre == 8 * TM) wait_vmcnt<8 * TM>();
+        else if (pre == 8 * TM + NDMA) wait_vmcnt<8 * TM + NDMA>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(sb, 0);
+        ah[0] = lds_read128<0>(a_off[0][0] + sb);
+        al[0] = lds_read128<0>(a_off[0][1] + sb);
+        static_for<0, NSUB>([&](auto u_tag) {
+            constexpr int u = decltype(u_tag)::value, kb = u / TM, i = u % TM, sl = u & 1;
+            if constexpr (u + 1 < NSUB) {       // prefetch the next sub-step's fragments, then wait for everything older than them
+                constexpr int nkb = (u + 1) / TM, ni = (u + 1) % TM, nsl = (u + 1) & 1;
+                if constexpr (ni == 0) read_b(sb, nkb);
+                ah[nsl] = lds_read128<ni * 4096>(a_off[nkb][0] + sb);
+                al[nsl] = lds_read128<ni * 4096>(a_off[nkb][1] + sb);
+                if constexpr (ni == 0) wait_lgkmcnt<6>(); else wait_lgkmcnt<2>();
+            } else {
+                wait_lgkmcnt<0>();
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], ah[sl], acc[i][j], 0, 0, 0);
+                    else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kb][j], ah[sl], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], al[sl], acc[i][j], 0, 0, 0);
+                    const int piece = u * 3 + t;     // one DMA piece per two MFMAs from the start of the step
+                    if (ISSUE && j == 1 && piece < NDMA) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(piece, kt_issue, buf ^ 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    int m0, n0;
+    tile_origin(t, m0, n0);
+    set_src(m0, n0);
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) issue_piece(q, 0, 0);
+    issue_bias(0);
+    if (nk > 1) {
+#pragma unroll
+        for (int q = 0; q < NDMA; ++q) issue_piece(q, 1, 1);
+    }
+    // vector-memory instructions issued after the stage that K step 0 / K step 1 of the current tile reads (see kstep's `pre`)
+    int pre0 = 1 + (nk > 1 ? NDMA : 0), pre1 = 0;
+    int gs = 0, tile_no = 0;        // ring parity (K steps run so far), bias slot parity
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const int t_next = t + gridDim.x;
+        const bool has_next = t_next < ntiles;
+        int nm0 = 0, nn0 = 0;
+        if (has_next) tile_origin(t_next, nm0, nn0);
+        // K steps 0 .. nk-2 fetch K tiles 2 .. nk-1, 0' (stages 0 and 1 of a tile are in the ring when it starts; step kt fetches K tile
+        // kt + 2 into the buffer step kt - 1 ... no: into the buffer of step kt + 1?  The ring has TWO buffers: step kt reads buffer
+        // (gs & 1); the buffer of step kt + 1 was filled during step kt - 1 (or before the tile started); so step kt fetches K tile kt + 1
+        // ONLY if it has not been fetched yet: K tile 1 was fetched up front, hence step 0 issues nothing and step kt >= 1 fetches kt + 1.
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const int pre = kt == 0 ? pre0 : (kt == 1 ? pre1 : 0);
+            if (kt == 0) kstep(gs & 1, std::false_type{}, 0, pre);
+            else kstep(gs & 1, std::true_type{}, kt + 1, pre);
+            ++gs;
+        }
+        // last K step: the ring runs on into the next tile (its stage 0 goes into the buffer of the step before this one)
+        {
+            const int pre = nk == 1 ? pre0 : (nk == 2 ? pre1 : 0);
+            if (has_next) { set_src(nm0, nn0); kstep(gs & 1, std::true_type{}, 0, pre); issue_bias((tile_no + 1) & 1); }
+            else kstep(gs & 1, std::false_type{}, 0, pre);
+            ++gs;
+        }
+        // stage 1 of the next tile into the buffer the last step has just read (every wave is done with it after this barrier)
+        int behind = 0;                 // vector-memory instructions issued behind the next tile's stage 0
+        if (has_next) {
+            behind = 1;                 // the bias piece
+            if (nk > 1) {
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NDMA; ++q) issue_piece(q, 1, gs & 1 ? 0 : 1);
+                __builtin_amdgcn_sched_barrier(0);
+                behind += NDMA;
+            }
+        }
+        // ---- epilogue of tile (m0, n0) ----
+        const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+        const bool full = m0 + BM <= g.M && n0 + BN <= g.N;
+        const unsigned char* bslot = smem_p8 + BIAS_OFF + (tile_no & 1) * 2048 + wave * 256;
+        int stores = -1;                // store instructions issued by the fast path (-1: unknown, drain)
+        if (epi.vec && !g.R && !g.gate && full) {
+            // fast path: bias from LDS, activation, exactly 4 store instructions per sub-tile, no loads.  The bias slot was written by
+            // this wave's own DMA, which is older than everything waited for since (it came with the tile's stage 0).
+            f32x16* a = &acc[0][0];
+#pragma nounroll
+            for (int st = 0; st < NSUB; ++st) {      // ONE copy of the code: the sub-tile to finish is always acc[0][0]
+                const int i = st >> 1, j = st & 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                    if (g.bias) b = *reinterpret_cast<const f32x4*>(bslot + (j * 32 + 8 * q + 4 * h) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[0][4 * q + e] = a[0][4 * q + e] * kOutScale + b[e];
+                }
+                epilogue_tile32_store<false>(g, g.C, m0 + wm * (32 * TM) + i * 32 + r, n0 + wn * 64 + j * 32, h, a[0]);
+#pragma unroll
+                for (int u = 0; u + 1 < NSUB; ++u) a[u] = a[u + 1];
+            }
+            stores = 4 * NSUB;
+        } else {
+            epilogue_tiles<true, false, TM, 2>(g, epi, m0 + wm * (32 * TM) + r, n0 + wn * 64, h, acc, kOutScale);
+        }
+        if (!has_next) break;
+        // the next tile's K step 0 needs its stage 0: everything issued behind it may stay in flight if it can be counted
+        if (stores >= 0) { pre0 = behind + stores; pre1 = stores; }
+        else { pre0 = 0; pre1 = 0; }
+        t = t_next; m0 = nm0; n0 = nn0; ++tile_no;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Two-workgroups-per-CU variant: 128x128 tile, 4 waves (2 x 2, wave tile 64 x 64 = 64 accumulator registers), 2 stages of
 // 32 KiB = 64 KiB of LDS per workgroup, so two workgroups are co-resident on a CU and run out of phase: while one sits in its
 // epilogue (a tile's 64 KiB of stores drain in ~3.6 us whatever their shape: the write path, not instruction issue, bounds
 // them), in its prologue, at its barrier or waiting for a DMA stage, the other one owns the matrix cores.  Same two-stage
 // K-step structure as the 256x256 kernel: vmcnt(0) + one barrier at the top of a step, the 8 DMA pieces of the next stage
 // issued in the MFMA gaps of this one, fragments rolling through registers behind counted lgkmcnt waits.
-// Tile order of the persistent 128x128 kernel (and of the tail launch that finishes its last round): tile index t -> origin.
+// Tile order of the persistent 128x128 kernel: tile index t -> origin.
 // XCD-contiguous (workgroups b and b + 8 share an XCD, so consecutive tile indices of one XCD walk one tile group) and grouped
 // column-major inside groups of GM row tiles, so that an XCD's L2 sees few distinct weight / activation rows at a time.
 __device__ __forceinline__ void p8_tile_origin128(int t, int ntiles, int tiles_m, int tiles_n, int& m0, int& n0, int GM = 4) {
@@ -680,171 +704,6 @@ __device__ __forceinline__ void p8_tile_origin128(int t, int ntiles, int tiles_m
     m0 = (first_m + (in_g - tn * gsz)) * 128;
     n0 = tn * 128;
 }
-
-template <int ABL = 0, int TAG = 0>
-__global__ __launch_bounds__(256, 2) void gemm_p8_2wg_kernel(const GemmArgs g) {
-    constexpr int BM = 128, BN = 128, BK = 32;
-    constexpr int STAGE_BYTES = (BM + BN) * 128;     // 32 KiB
-    constexpr int NDMA = 8;                           // 1-KiB pieces per wave per stage: 4 of A, 4 of W
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
-
-    const int tid = threadIdx.x;
-    unsigned long long* stamps = nullptr;
-    if constexpr (ABL == 6) {
-        stamps = reinterpret_cast<unsigned long long*>(g.partial) + (long)blockIdx.x * 8;
-        if (tid == 0) {
-            stamps[0] = wall_clock64();
-            stamps[4] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
-            stamps[5] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
-        }
-    }
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
-    int tm, tn;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        constexpr int GM = 4;     // row tiles per tile group of an XCD (8 measured the same)
-        const int width = GM * tiles_n;
-        const int group = idx / width, first_m = group * GM;
-        const int gsz = min(tiles_m - first_m, GM);
-        const int in_g = idx - group * width;
-        tn = in_g / gsz;
-        tm = first_m + (in_g - tn * gsz);
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
-    // column group of this tile (kernels.h): global column indices stay, the operand / result bases move
-    const int grp = g.ngrp ? n0 / g.ngrp : 0;
-    const long wgrp_off = grp ? (long)grp * (g.grpW - (long)g.ngrp * g.ldw) : 0;
-
-    const int nk_all = g.K / BK;   // split-K (small grids): this workgroup owns K tiles [kt0, kt0 + nk)
-    const int kt0 = (int)((long)nk_all * blockIdx.y / g.splitk);
-    const int nk = (int)((long)nk_all * (blockIdx.y + 1) / g.splitk) - kt0;
-    // ---- DMA addressing: piece = 8 rows x 128 B; wave w owns A rows 32w..32w+31 and W rows 32w..32w+31 of the tile ----
-    const int prow = lane >> 3, pchunk = lane & 7;
-    const unsigned char* src[NDMA];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ra = wave * 32 + q * 8 + prow;
-        const int gm = min(m0 + ra, g.M - 1);          // clamp: rows >= M are never stored
-        const int gn = min(n0 + ra, g.N - 1);
-        const int sw = (pchunk ^ ((ra >> 1) & 7)) << 4;
-        src[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda + (long)kt0 * BK) * 4 + sw;
-        src[4 + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw + (long)kt0 * BK + wgrp_off) * 4 + sw;
-    }
-    auto issue_piece = [&](int q, int kt, int buf) {
-        unsigned char* dst = smem_p8 + buf * STAGE_BYTES + (q < 4 ? 0 : BM * 128) + (wave * 4 + (q & 3)) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (long)kt * (BK * 4)),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    };
-
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_p8;
-    unsigned a_off[2][2], w_off[2][2];               // [kb][hi/lo]; the second tile is +4096 B (32 rows, same swizzle key)
-    {
-        const int arow = wm * 64 + r, wrow = wn * 64 + r;
-        const int akey = (arow >> 1) & 7, wkey = (wrow >> 1) & 7;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int lo = 0; lo < 2; ++lo) {
-                const int c = (kb * 2 + h) * 2 + lo;
-                a_off[kb][lo] = lds0 + arow * 128 + ((c ^ akey) << 4);
-                w_off[kb][lo] = lds0 + BM * 128 + wrow * 128 + ((c ^ wkey) << 4);
-            }
-    }
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-#pragma unroll
-    for (int q = 0; q < NDMA; ++q) issue_piece(q, 0, 0);
-
-    f16x8 bh[2][2], bl[2][2];      // [k block parity][n tile]
-    f16x8 ah[2], al[2];            // [m tile]
-    auto read_b = [&](unsigned sb, int kb) {
-        bh[kb][0] = lds_read128<0>(w_off[kb][0] + sb);
-        bl[kb][0] = lds_read128<0>(w_off[kb][1] + sb);
-        bh[kb][1] = lds_read128<4096>(w_off[kb][0] + sb);
-        bl[kb][1] = lds_read128<4096>(w_off[kb][1] + sb);
-    };
-    auto read_a = [&](unsigned sb, int kb, int i) {
-        const unsigned hp = a_off[kb][0] + sb, lp = a_off[kb][1] + sb;
-        if (i == 0) { ah[0] = lds_read128<0>(hp); al[0] = lds_read128<0>(lp); }
-        else { ah[1] = lds_read128<4096>(hp); al[1] = lds_read128<4096>(lp); }
-    };
-    auto substep = [&](int kt, int buf, unsigned sb, auto issue_tag, auto kb_tag, auto i_tag) {
-        constexpr bool ISSUE = decltype(issue_tag)::value;
-        constexpr int kb = decltype(kb_tag)::value, i = decltype(i_tag)::value;
-        if constexpr (i == 0) { read_a(sb, kb, 1); wait_lgkmcnt<2>(); }
-        else if constexpr (kb == 0) { read_b(sb, 1); read_a(sb, 1, 0); wait_lgkmcnt<6>(); }
-        else wait_lgkmcnt<0>();
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], ah[i], acc[i][j], 0, 0, 0);
-                else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kb][j], ah[i], acc[i][j], 0, 0, 0);
-                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], al[i], acc[i][j], 0, 0, 0);
-                const int piece = (kb * 2 + i) * 3 + t;     // one DMA piece per two MFMAs over the first 16 MFMAs of the step
-                if (ISSUE && j == 1 && piece < NDMA) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_piece(piece, kt + 1, buf ^ 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto kstep = [&](int kt, int buf, auto issue_tag) {
-        const unsigned sb = buf * STAGE_BYTES;
-        wait_vmcnt<0>();                                   // stage kt (issued during step kt-1) landed for this wave
-        __builtin_amdgcn_s_barrier();                      // ... for all waves, and all are done reading stage kt-1
-        __builtin_amdgcn_sched_barrier(0);
-        read_b(sb, 0);
-        read_a(sb, 0, 0);
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-        substep(kt, buf, sb, issue_tag, I0{}, I0{});
-        substep(kt, buf, sb, issue_tag, I0{}, I1{});
-        substep(kt, buf, sb, issue_tag, I1{}, I0{});
-        substep(kt, buf, sb, issue_tag, I1{}, I1{});
-    };
-    int kt = 0;
-    for (; kt + 1 < nk; ++kt) {
-        if (ABL == 6 && kt == 1) { if (tid == 0) stamps[1] = wall_clock64(); }
-        kstep(kt, kt & 1, std::true_type{});
-    }
-    kstep(kt, kt & 1, std::false_type{});
-    if constexpr (ABL == 6) { if (tid == 0) stamps[2] = wall_clock64(); }
-
-    const EpiCtx epi = make_epi(g, g.bias ? g.bias + (long)grp * (g.grpB - g.ngrp) : nullptr, g.C + (long)grp * (g.grpC - g.ngrp), g.R);
-    float* __restrict__ P = g.splitk > 1 ? g.partial + (long)blockIdx.y * g.M * g.N : nullptr;
-    auto epi_tile = [&](auto i_tag, auto j_tag) {
-        constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
-        if constexpr (ABL == 7) { asm volatile("" ::"v"(acc[i][j])); return; }     // timing ablation: no epilogue at all
-        if (P) partial_tile32(g, P, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);     // raw sums: splitk_reduce_kernel finishes
-        else epilogue_tile32<true, false>(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * 64 + j * 32, h, acc[i][j]);
-    };
-    {   // four copies of the epilogue code on purpose: this kernel's epilogue is not hidden behind its own main loop, and the
-        // sub-tiles' loads and stores overlap when unrolled (the looped form of common.h cost the fp32 kernel 7 %)
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-        epi_tile(I0{}, I0{}); epi_tile(I0{}, I1{}); epi_tile(I1{}, I0{}); epi_tile(I1{}, I1{});
-    }
-    if constexpr (ABL == 6) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (tid == 0) stamps[3] = wall_clock64();
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------------------------
 // Persistent form of the two-workgroup kernel with a DEFERRED epilogue: 512 workgroups (two per CU) walk the tile list with
@@ -987,9 +846,8 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    const int gm_rows = g.tile_gm > 0 ? g.tile_gm : 4;
-    auto tile_origin = [&](int t, int& m0, int& n0) { p8_tile_origin128(t, ntiles, tiles_m, tiles_n, m0, n0, gm_rows); };
-    const int t_end = g.tile_end > 0 ? g.tile_end : ntiles;        // tail split: the rest is another launch's (kernels.h)
+    auto tile_origin = [&](int t, int& m0, int& n0) { p8_tile_origin128(t, ntiles, tiles_m, tiles_n, m0, n0); };
+    const int t_end = ntiles;
     auto set_src = [&](int m0, int n0) {
         const int grp = g.ngrp ? n0 / g.ngrp : 0;          // column group (kernels.h): global column indices stay, the bases move
         const long wgrp_off = grp ? (long)grp * (g.grpW - (long)g.ngrp * g.ldw) : 0;
@@ -1122,14 +980,7 @@ __global__ __launch_bounds__(256) void gemm_p8_sm_kernel(const GemmArgs g) {
         tn = in_g / gsz;
         tm = first_m + (in_g - tn * gsz);
     }
-    int m0 = tm * BM, n0 = tn * BN;
-    if (BM == 64 && BN == 64 && g.tail_t0 > 0) {
-        // tail launch of the persistent 128x128 kernel: workgroup b = sub-tile (b & 3) of that kernel's tile tail_t0 + (b >> 2)
-        const int t128_n = (g.N + 127) / 128, t128_m = (g.M + 127) / 128;
-        p8_tile_origin128(g.tail_t0 + (blockIdx.x >> 2), t128_n * t128_m, t128_m, t128_n, m0, n0);
-        m0 += (blockIdx.x & 1) * 64;
-        n0 += ((blockIdx.x >> 1) & 1) * 64;
-    }
+    const int m0 = tm * BM, n0 = tn * BN;
     const int nk_all = g.K / BK;   // split-K: this workgroup owns K tiles [kt0, kt0 + nk)
     const int kt0 = (int)((long)nk_all * blockIdx.y / g.splitk);
     const int nk = (int)((long)nk_all * (blockIdx.y + 1) / g.splitk) - kt0;
@@ -1212,7 +1063,7 @@ __global__ __launch_bounds__(256) void gemm_p8_sm_kernel(const GemmArgs g) {
     __builtin_amdgcn_s_barrier();
     read_frags(0, 0, ah0, al0, bh0, bl0);
     int kt = 0, buf = 0;
-    for (; kt + STAGES - 1 < nk; ++kt) {               // steady state (see gemm_p8_kernel)
+    for (; kt + STAGES - 1 < nk; ++kt) {               // steady state
         const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
         const int fbuf = (buf == 0) ? STAGES - 1 : buf - 1;
         read_frags(buf, 1, ah1, al1, bh1, bl1);
@@ -1296,7 +1147,6 @@ __device__ __forceinline__ f16x8 lds_read128_big(unsigned addr) {      // offset
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
-template <int TAG>
 __global__ __launch_bounds__(512) void posconv_p8_kernel(const GemmArgs g, int T, int Ts) {
     constexpr int CG = 64, KT = 128, PAD = 64, NSTEP = KT * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
@@ -1363,118 +1213,6 @@ __global__ __launch_bounds__(512) void posconv_p8_kernel(const GemmArgs g, int T
     // window address of this lane's activation row (tile 0) at tap 0, channel half 0, k block 0, hi: + tap * PC_PITCH per tap;
     // offsets: channel half 128, k block 64, lo 16, second row tile 32 * PC_PITCH
     const unsigned a_lane = lds0 + (wm * 64 + r) * PC_PITCH + h * 32;
-
-    if constexpr (TAG == 1) {
-        // ---- experiment (ARTALK_POSCONV_MFMA16=1): the same wave tile on v_mfma_f32_16x16x32_f16 (8 accumulators of 4 registers).
-        // Equal cycles per flop, but the chip holds a higher clock under this shape (profiles/r02_mfma_f16_peak.log) ----
-        typedef float f32x4v __attribute__((ext_vector_type(4)));
-        const int r16 = lane & 15, gq = lane >> 4;
-        unsigned w16[2][2];             // [n tile][hi/lo]
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int wrow = wn * 32 + nt * 16 + r16, wkey = (wrow >> 1) & 7;
-#pragma unroll
-            for (int lo = 0; lo < 2; ++lo) w16[nt][lo] = ring0 + wrow * 128 + (((gq * 2 + lo) ^ wkey) << 4);
-        }
-        const unsigned a16 = lds0 + (wm * 64 + r16) * PC_PITCH + gq * 32;     // + tap * PC_PITCH; tile mt: + 16 mt PC_PITCH; half: + 128; lo: + 16
-        f32x4v c16[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { const f32x4v z = {0.f, 0.f, 0.f, 0.f}; c16[i][j] = z; }
-        f16x8 wh[2][2], wl[2][2];       // [set][n tile]
-        f16x8 p01h[2][2], p01l[2][2];   // activations of m tiles 0, 1: [set][tile]
-        f16x8 p23h[2], p23l[2];         // m tiles 2, 3
-        auto rd_w = [&](auto buf_tag, auto set_tag) {
-            constexpr int S = decltype(set_tag)::value, OFF = decltype(buf_tag)::value * PC_STAGE;
-            wh[S][0] = lds_read128_big<OFF>(w16[0][0]); wl[S][0] = lds_read128_big<OFF>(w16[0][1]);
-            wh[S][1] = lds_read128_big<OFF>(w16[1][0]); wl[S][1] = lds_read128_big<OFF>(w16[1][1]);
-        };
-        auto rd_p01 = [&](unsigned abase, auto half_tag, auto set_tag) {
-            constexpr int S = decltype(set_tag)::value, HO = decltype(half_tag)::value * 128;
-            p01h[S][0] = lds_read128_big<HO>(abase);                 p01l[S][0] = lds_read128_big<HO + 16>(abase);
-            p01h[S][1] = lds_read128_big<HO + 16 * PC_PITCH>(abase); p01l[S][1] = lds_read128_big<HO + 16 * PC_PITCH + 16>(abase);
-        };
-        auto rd_p23 = [&](unsigned abase, auto half_tag) {
-            constexpr int HO = decltype(half_tag)::value * 128;
-            p23h[0] = lds_read128_big<HO + 32 * PC_PITCH>(abase); p23l[0] = lds_read128_big<HO + 32 * PC_PITCH + 16>(abase);
-            p23h[1] = lds_read128_big<HO + 48 * PC_PITCH>(abase); p23l[1] = lds_read128_big<HO + 48 * PC_PITCH + 16>(abase);
-        };
-        using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
-        using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
-        __syncthreads();
-        wait_vmcnt<2>();
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        rd_w(J0{}, J0{});
-        rd_p01(a16, J0{}, J0{});
-        auto kstep16 = [&](int ks, auto j_tag) {
-            constexpr int J = decltype(j_tag)::value, S = J & 1;
-            using NSET = std::integral_constant<int, 1 - S>;
-            using HALF = std::integral_constant<int, J & 1>;
-            using NHALF = std::integral_constant<int, (J + 1) & 1>;
-            using NBUF = std::integral_constant<int, (J + 1) & 3>;
-            const unsigned abase = a16 + (ks >> 1) * PC_PITCH;
-            if (ks + 2 < NSTEP) wait_vmcnt<1>(); else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + PC_STAGES - 1 < NSTEP) {
-                issue_stage(ks + PC_STAGES - 1, (J + PC_STAGES - 1) & (PC_STAGES - 1));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            rd_p23(abase, HALF{});
-            wait_lgkmcnt<4>();
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    c16[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[S][nt], p01h[S][mt], c16[mt][nt], 0, 0, 0);
-                    c16[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[S][nt], p01h[S][mt], c16[mt][nt], 0, 0, 0);
-                    c16[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[S][nt], p01l[S][mt], c16[mt][nt], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < NSTEP) {
-                rd_w(NBUF{}, NSET{});
-                rd_p01(a16 + ((ks + 1) >> 1) * PC_PITCH, NHALF{}, NSET{});
-                wait_lgkmcnt<8>();
-            } else {
-                wait_lgkmcnt<0>();
-            }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    c16[2 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[S][nt], p23h[mt], c16[2 + mt][nt], 0, 0, 0);
-                    c16[2 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[S][nt], p23h[mt], c16[2 + mt][nt], 0, 0, 0);
-                    c16[2 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[S][nt], p23l[mt], c16[2 + mt][nt], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        for (int ks = 0; ks < NSTEP; ks += 4) {
-            kstep16(ks, J0{});
-            kstep16(ks + 1, J1{});
-            kstep16(ks + 2, J2{});
-            kstep16(ks + 3, J3{});
-        }
-        // epilogue: lane (r16, gq) of tile (mt, nt) holds frame wm*64 + 16 mt + r16, channels n0 + 16 nt + 4 gq .. + 3
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int t = wm * 64 + 16 * mt + r16;
-            if (t >= Ts) continue;
-            const long row = row0 + t;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int col = grp * CG + wn * 32 + 16 * nt + 4 * gq;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + col);
-                const f32x4 rv = *reinterpret_cast<const f32x4*>(g.R + row * g.ldr + col);
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = gelu_erf(c16[mt][nt][e] * kOutScale + bv[e]) + rv[e];
-                *reinterpret_cast<f32x4*>(g.C + row * g.ldc + col) = o;
-            }
-        }
-        return;
-    }
 
     f32x16 acc[2];
 #pragma unroll
@@ -1581,13 +1319,10 @@ void launch_posconv_p8(const GemmArgs& g, int n_chunks, int T, int Ts, hipStream
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&posconv_p8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&posconv_p8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&posconv_p8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev] = true;
     }
-    static const int mfma16 = getenv("ARTALK_POSCONV_MFMA16") ? atoi(getenv("ARTALK_POSCONV_MFMA16")) : 0;      // experiment, see the kernel
-    if (mfma16) hipLaunchKernelGGL((posconv_p8_kernel<1>), dim3(n_chunks * 16), dim3(512), lds, s, g, T, Ts);
-    else hipLaunchKernelGGL((posconv_p8_kernel<0>), dim3(n_chunks * 16), dim3(512), lds, s, g, T, Ts);
+    hipLaunchKernelGGL(posconv_p8_kernel, dim3(n_chunks * 16), dim3(512), lds, s, g, T, Ts);
 }
 
 template <int BM, int BN, int STAGES>
@@ -1600,20 +1335,15 @@ static void launch_p8_sm_cfg(const GemmArgs& g, hipStream_t s) {
 bool gemm_p8_sm_eligible(const GemmArgs& g) {
     return g.Wp != nullptr && g.a_packed && g.amode == 0 && g.batch == 1 && g.K % 32 == 0 && (g.lda % 8) == 0;
 }
-// force_cfg 20: 64x64 x 4 stages (default), 21: 128x64 x 3 stages, 22: 128x128 x 3 stages; deep rings for the split-K launches of
-// the small scale steps, where a workgroup's whole K slice should be in flight at once (the launch then costs one memory
-// latency instead of one per K step): 23: 64x64 x 8 stages (128 KiB, one workgroup per CU), 24: 64x64 x 5 stages (80 KiB, two
-// per CU), 25: 64x128 x 5 stages (120 KiB), 26: 128x64 x 5 stages (120 KiB)
+// force_cfg 20: 64x64 x 4 stages (default); deep rings for the split-K launches of the small scale steps, where a workgroup's whole K
+// slice should be in flight at once (the launch then costs one memory latency instead of one per K step): 23: 64x64 x 8 stages
+// (128 KiB, one workgroup per CU), 24: 64x64 x 5 stages (80 KiB, two per CU).  (128x64, 64x128 and 128x128 tiles and a 3-stage ring
+// were measured on the unsplit grids of the 50- / 100-token steps and never won: DESIGN.md section 6.)
 void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return;
     switch (g.force_cfg) {
-        case 21: launch_p8_sm_cfg<128, 64, 3>(g, s); break;
-        case 22: launch_p8_sm_cfg<128, 128, 3>(g, s); break;
         case 23: launch_p8_sm_cfg<64, 64, 8>(g, s); break;
         case 24: launch_p8_sm_cfg<64, 64, 5>(g, s); break;
-        case 25: launch_p8_sm_cfg<64, 128, 5>(g, s); break;
-        case 26: launch_p8_sm_cfg<128, 64, 5>(g, s); break;
-        case 27: launch_p8_sm_cfg<64, 64, 3>(g, s); break;
         default: launch_p8_sm_cfg<64, 64, 4>(g, s); break;
     }
 }
@@ -1627,7 +1357,7 @@ static bool epi_vec_host(const GemmArgs& g) {
     if (g.gate) bits |= (unsigned long long)g.ldg | ((unsigned long long)g.gate >> 2);
     return (bits & 3) == 0;
 }
-void gemm_p8_prepare() {      // more than the default 64 KB of dynamic LDS for the persistent kernel's residual slots (outside any capture)
+void gemm_p8_prepare() {      // more than the default 64 KB of dynamic LDS (outside any capture)
     static bool done[64] = {};      // per device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1636,6 +1366,9 @@ void gemm_p8_prepare() {      // more than the default 64 KB of dynamic LDS for 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_2wgp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128 + 16384);
     done[dev] = true;
 }
+// The two production kernels: force_cfg 7 = gemm_p8_256_kernel (256x256 tiles), 8 = gemm_p8_2wgp_kernel (persistent 128x128, two
+// workgroups per CU, deferred epilogue), -1 = gemm_p8_variant()'s choice; 17 = the 256x256 kernel with wall-clock stamps
+// (tools/gemm_p8_stamps.py).  Needs the 16-byte epilogue path (epi_vec_host) for cfg 8.
 void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
     if (g0.M <= 0 || g0.N <= 0) return;
     // No range guard in the epilogues of the large-grid kernels (compiled out: epilogue_tile32<.., GUARD = false>; with it the dominant
@@ -1644,66 +1377,23 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
     // guard - one kernel later instead of in place.
     GemmArgs g = g0;
     g.status = nullptr;
-    const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t256 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
-    const int t256sq = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t256sq = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     int cfg = g.force_cfg;
-    if (cfg < 0) cfg = gemm_p8_variant(g) == 1 ? 7 : 8;
-    static const int persist = getenv("ARTALK_P8_PERSIST") ? atoi(getenv("ARTALK_P8_PERSIST")) : 1;     // tuning: 0 = one workgroup per tile
-    switch (cfg) {   // 7 / 8 are the production kernels; the others are kept for tuning (tools/gemm_f16s_bench.py)
-        case 2: hipLaunchKernelGGL((gemm_p8_kernel<128, 4>), dim3(t128), dim3(512), 4 * 256 * 128, s, g); break;
-        case 3: hipLaunchKernelGGL((gemm_p8_kernel<128, 3>), dim3(t128), dim3(512), 3 * 256 * 128, s, g); break;
-        case 5: hipLaunchKernelGGL((gemm_p8_kernel<128, 5>), dim3(t128), dim3(512), 5 * 256 * 128, s, g); break;
-        case 6: hipLaunchKernelGGL((gemm_p8_kernel<256, 3>), dim3(t256), dim3(512), 3 * 384 * 128, s, g); break;
-        case 16: hipLaunchKernelGGL((gemm_p8_kernel<128, 4, 6>), dim3(t128), dim3(512), 4 * 256 * 128, s, g); break;
-        case 7: {
-            static const int gm256 = getenv("ARTALK_P8_256_GM") ? atoi(getenv("ARTALK_P8_256_GM")) : 0;
-            GemmArgs a = g;
-            a.tile_gm = gm256;
-            hipLaunchKernelGGL((gemm_p8_256_kernel<0>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, a);
-            break;
-        }
-        case 17: hipLaunchKernelGGL((gemm_p8_256_kernel<6>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;
-        case 10: hipLaunchKernelGGL((gemm_p8_256_kernel<1>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g); break;   // tuning: direct-store epilogue
-        case 18: hipLaunchKernelGGL((gemm_p8_2wg_kernel<6>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;
-        case 9: {      // persistent, deferred epilogue
-            static const int res_defer9 = getenv("ARTALK_P8_RES_DEFER") ? atoi(getenv("ARTALK_P8_RES_DEFER")) : 1;
-            GemmArgs a = g;
-            a.res_lds = (res_defer9 && g.R && !g.gate && !g.c_p8 && epi_vec_host(g)) ? 1 : 0;
-            if (a.res_lds) gemm_p8_prepare();
-            hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), 2 * 256 * 128 + (a.res_lds ? 16384 : 0), s, a);
-            break;
-        }
-        case 19: hipLaunchKernelGGL((gemm_p8_2wg_kernel<7>), dim3(t128), dim3(256), 2 * 256 * 128, s, g); break;   // ablation: no epilogue
-        default:
-            if (cfg == 8 && g.force_cfg < 0 && g.splitk == 1 && persist && epi_vec_host(g) && (!g.graph_tag || t128 >= 1024)) {
-                // production choice: persistent, deferred epilogue (inside the captured AR/VAE body only for grids several rounds deep)
-                GemmArgs a = g;
-                static const int tile_gm = getenv("ARTALK_P8_GM") ? atoi(getenv("ARTALK_P8_GM")) : 0;      // tuning: row tiles per XCD tile group
-                a.tile_gm = tile_gm;
-                const int rem = t128 % 512;
-                // tail split (tuning, off: ARTALK_P8_TAIL=n turns it on for last rounds of up to n tiles): the last, partly filled round
-                // finished by 64x64 sub-tiles.  Measured slower (encoder 43.4 -> 45.6 ms per step at 320): the workgroups of a partly
-                // filled round have their CU to themselves and finish early, while the extra launch pays its boundary and the small kernel's rate
-                static const int tail_max = getenv("ARTALK_P8_TAIL") ? atoi(getenv("ARTALK_P8_TAIL")) : 0;
-                const bool tail = t128 > 512 && rem > 0 && rem <= tail_max && g.ngrp == 0;
-                if (tail) a.tile_end = t128 - rem;
-                // residual tiles deferred too (tuning: ARTALK_P8_RES_DEFER=0 finishes them at once): 16 KiB more LDS, still two workgroups per CU
-                static const int res_defer = getenv("ARTALK_P8_RES_DEFER") ? atoi(getenv("ARTALK_P8_RES_DEFER")) : 1;
-                a.res_lds = (res_defer && g.R && !g.gate && !g.c_p8) ? 1 : 0;
-                if (a.res_lds) gemm_p8_prepare();
-                const size_t lds = 2 * 256 * 128 + (a.res_lds ? 16384 : 0);
-                if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wgp_kernel<1>), dim3(t128 < 512 ? t128 : 512), dim3(256), lds, s, a);
-                else hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), lds, s, a);
-                if (tail) {
-                    GemmArgs b = g;
-                    b.tail_t0 = t128 - rem;
-                    if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_sm_kernel<64, 64, 4, 1>), dim3(rem * 4, 1), dim3(256), 4 * 128 * 128, s, b);
-                    else hipLaunchKernelGGL((gemm_p8_sm_kernel<64, 64, 4, 0>), dim3(rem * 4, 1), dim3(256), 4 * 128 * 128, s, b);
-                }
-            }
-            else if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wg_kernel<0, 1>), dim3(t128, g.splitk), dim3(256), 2 * 256 * 128, s, g);
-            else hipLaunchKernelGGL((gemm_p8_2wg_kernel<0, 0>), dim3(t128, g.splitk), dim3(256), 2 * 256 * 128, s, g);
-            break;
+    if (cfg != 7 && cfg != 8 && cfg != 17) cfg = gemm_p8_variant(g) == 1 ? 7 : 8;
+    if (cfg == 8 && !epi_vec_host(g)) cfg = 7;      // (no launch of the path gets here: every large-grid result is 16-byte aligned)
+    if (cfg == 7) {
+        hipLaunchKernelGGL((gemm_p8_256_kernel<0>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g);
+    } else if (cfg == 17) {
+        hipLaunchKernelGGL((gemm_p8_256_kernel<6>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g);
+    } else {
+        // residual tiles deferred too (ARTALK_P8_RES_DEFER=0 finishes them at once; tests compare both): 16 KiB more LDS, still two
+        // workgroups per CU
+        static const int res_defer = getenv("ARTALK_P8_RES_DEFER") ? atoi(getenv("ARTALK_P8_RES_DEFER")) : 1;
+        g.res_lds = (res_defer && g.R && !g.gate && !g.c_p8) ? 1 : 0;
+        if (g.res_lds) gemm_p8_prepare();
+        const size_t lds = 2 * 256 * 128 + (g.res_lds ? 16384 : 0);
+        if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wgp_kernel<1>), dim3(t128 < 512 ? t128 : 512), dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), lds, s, g);
     }
 }
 // 0: two-workgroup 128x128 kernel, 1: 256x256 kernel.  The big tile halves the operand bytes per flop (its main loop runs faster)
@@ -1713,8 +1403,8 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
 // the 300-tile out-projection / FFN-out GEMMs (266 / 305 vs 311 / 338).
 int gemm_p8_variant(const GemmArgs& g) {
     const long t256sq = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
-    static const long min256 = getenv("ARTALK_P8_256_MIN") ? atol(getenv("ARTALK_P8_256_MIN")) : 800;      // tuning
-    return (t256sq >= min256 && g.N % 256 == 0 && g.ngrp == 0) ? 1 : 0;      // column groups: the 128x128 kernels only
+    static const long min256 = getenv("ARTALK_P8_256_MIN") ? atol(getenv("ARTALK_P8_256_MIN")) : 800;      // tuning / tests: dispatch threshold
+    return (t256sq >= min256 && g.N % 256 == 0 && g.ngrp == 0) ? 1 : 0;      // column groups: the 128x128 kernel only
 }
 bool gemm_p8_eligible(const GemmArgs& g) {
     return g.Wp != nullptr && g.a_packed && g.amode == 0 && g.batch == 1 && g.splitk == 1 && g.K % 32 == 0 && (g.lda % 8) == 0 &&

@@ -46,15 +46,10 @@ struct GemmArgs {
     // split-K (small-M steps of the AR loop): grid.y = splitk workgroups share one output tile, each writes its raw partial
     // sums to partial[y][M][N]; launch_splitk_reduce adds them in a fixed order (deterministic) and applies the epilogue.
     int splitk = 1; float* partial = nullptr;
-    // column groups (the two 128x128 LDS-DMA kernels only): columns [j*ngrp, (j+1)*ngrp) are an independent linear layer j that
+    // column groups (the persistent 128x128 LDS-DMA kernel only): columns [j*ngrp, (j+1)*ngrp) are an independent linear layer j that
     // shares A - weight rows at W + j*grpW, bias at bias + j*grpB, result columns at C + j*grpC (elements; ngrp % 128 == 0).
     // One launch then computes the same input through many layers' weights (the history K/V of all 12 AR blocks).
     int ngrp = 0; long grpW = 0, grpB = 0, grpC = 0;
-    // tail split of the persistent 128x128 kernel (launch_gemm_p8): it walks tiles [0, tile_end) of its (swizzled) tile order in
-    // whole rounds of 512 workgroups; the remaining tiles [tail_t0, ntiles) are cut into four 64x64 sub-tiles each and run by the
-    // small-grid kernel, so the last, partly filled round costs a quarter-tile's time instead of a whole tile's.  0 = unused.
-    int tile_end = 0, tail_t0 = 0;
-    int tile_gm = 0;     // tuning: row tiles per XCD tile group of the persistent kernel (0 = 4)
     int res_lds = 0;     // persistent kernel: 16 KiB of LDS behind the two stages are there for the deferred residual tiles (launch_gemm_p8)
     int force_cfg = -1;  // >= 0: tile configuration override (tuning/tests)
     int graph_tag = 0;   // 1 for launches inside the captured AR/VAE body (separate kernel symbol, same code)
@@ -75,9 +70,9 @@ void launch_gemm_f16s(const GemmArgs& g, hipStream_t s);
 bool gemm_p8_eligible(const GemmArgs& g);      // both operands in P8 and a large grid: the LDS-DMA kernels (gemm_p8_2wgp / _256)
 void launch_gemm_p8(const GemmArgs& g, hipStream_t s);
 void gemm_p8_prepare();      // one-time kernel attributes (call once per process before the first captured launch)
-int gemm_p8_variant(const GemmArgs& g);
+int gemm_p8_variant(const GemmArgs& g);       // 0: gemm_p8_2wgp_kernel (persistent 128x128, two workgroups per CU), 1: gemm_p8_256_kernel
 bool gemm_p8_sm_eligible(const GemmArgs& g);   // both operands in P8, any grid (split-K capable): small-tile LDS-DMA kernel
-void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s);        // 0: gemm_p8_2wg_kernel (128x128, two workgroups per CU), 1: gemm_p8_256_kernel
+void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s);
 // wav2vec2 positional convolution (16 groups of 64 channels, 128 taps) with the chunk's input window resident in LDS (gemm_f16s.hip)
 void launch_posconv_p8(const GemmArgs& g, int n_chunks, int T, int Ts, hipStream_t s);
 int gemm_config(const GemmArgs& g);   // 4: 128x128 BK16 (dominant kernel), 2: 64x64, 1: 128x64, 3: 32x128; 0,5,6,7 tuning variants
@@ -101,11 +96,6 @@ struct LnArgs {
     int junk_period = 0, junk_from = 0;
 };
 void launch_layernorm(const LnArgs& a, hipStream_t s);
-// Skinny split GEMM of the 1- / 5-token AR scale steps (ar_skinny.hip): one 16 x 16 result sliver per workgroup over the whole K,
-// optionally with the AdaLN-modulated LayerNorm `ln` of its input fused in front (then g.A is unused and ln->Y is not written).
-bool ar_skinny_eligible(const GemmArgs& g, const LnArgs* ln);
-void launch_ar_skinny(const GemmArgs& g, const LnArgs* ln, hipStream_t s);
-
 // softmax(scale * Q K^T [+mask]) V, fp32 MFMA, online softmax over 64-key blocks staged in LDS.
 struct AttnArgs {
     const float* Q = nullptr; long ldq = 0, q_bstride = 0;

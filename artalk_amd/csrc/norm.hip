@@ -124,13 +124,7 @@ void launch_layernorm(const LnArgs& a, hipStream_t s) {
         case 128: launch_ln<128, 1>(a, s); break;
         case 512: if (big) launch_ln<512, 4>(a, s); else launch_ln<512, 1>(a, s); break;
         case 768: if (big) launch_ln<768, 2>(a, s); else launch_ln<768, 1>(a, s); break;
-        case 1024: {
-            static const int rpw = getenv("ARTALK_LN1024_RPW") ? atoi(getenv("ARTALK_LN1024_RPW")) : 1;      // tuning: rows per wave on large inputs (wav2vec2 encoder: 1 measured 0.35 ms per step faster than 2, 4 slower)
-            if (!big || rpw == 1) launch_ln<1024, 1>(a, s);
-            else if (rpw == 4) launch_ln<1024, 4>(a, s);
-            else launch_ln<1024, 2>(a, s);
-            break;
-        }
+        case 1024: launch_ln<1024, 1>(a, s); break;      // one row per wave (wav2vec2 encoder: 0.35 ms per step faster than 2, 4 slower still)
         default: abort();
     }
 }

@@ -3,7 +3,8 @@
 Clips share nothing but read-only weights and chunks inside a clip are sequential, so the path shards by clip:
 one process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm), weights replicated
 (2 GB of 288 GB), no data-path collective.  The only exchange is the optional collection of results: one
-all-gather of the padded FLAME codes and one of the lengths.  The same code runs on the gloo backend with
+all-gather of the padded FLAME codes (the frame counts follow from the sample counts on the host, so nothing is
+read back and the host never waits for the device at N > 1 either).  The same code runs on the gloo backend with
 CPU tensors (tests/test_dist_gloo.py) and is what ``bench.py`` runs for N > 1.
 """
 from __future__ import annotations
@@ -44,10 +45,16 @@ def init_single_process_group(backend: str = "nccl", device: Optional[torch.devi
     dist.init_process_group(backend, rank=0, world_size=1, **kw)
 
 
-def gather_clips(local: Sequence[torch.Tensor], max_frames: int, group=None, force_collective: bool = False) -> List[torch.Tensor]:
+def gather_clips(local: Sequence[torch.Tensor], max_frames: int, group=None, force_collective: bool = False,
+                 all_lengths: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
     """All-gather per-clip results ``(T_i, D)`` of every rank; returns the clips of all ranks in rank order on
     every rank.  Every rank must pass the same number of clips (pad the shard with empty ``(0, D)`` tensors).
-    With one rank nothing is exchanged unless ``force_collective`` (then the collective runs over the 1-rank group)."""
+    With one rank nothing is exchanged unless ``force_collective`` (then the collective runs over the 1-rank group).
+
+    ``all_lengths`` = frames of all ``world * n`` (padded) slots, known on the host (a clip's frame count follows from its sample
+    count): then ONE collective runs and nothing is read back, so the host never waits for the device here and a serving loop
+    keeps its batches in flight at N > 1 as at N = 1.  Without it the lengths are all-gathered too and read back (one host
+    synchronisation per call)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1 and not (force_collective and dist.is_initialized()):
         return list(local)
@@ -55,25 +62,30 @@ def gather_clips(local: Sequence[torch.Tensor], max_frames: int, group=None, for
     D = local[0].shape[1]
     dev = local[0].device
     buf = torch.zeros(n, max_frames, D, dtype=local[0].dtype, device=dev)
-    lens = torch.zeros(n, dtype=torch.int64, device=dev)
     for i, t in enumerate(local):
         assert t.shape[0] <= max_frames, f"clip of {t.shape[0]} frames does not fit the gather buffer ({max_frames})"
         buf[i, : t.shape[0]] = t
-        lens[i] = t.shape[0]
     all_buf = torch.empty(world * n, max_frames, D, dtype=buf.dtype, device=dev)
-    all_len = torch.empty(world * n, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(all_buf, buf, group=group)
-    dist.all_gather_into_tensor(all_len, lens, group=group)
-    all_len = all_len.cpu().tolist()
+    if all_lengths is not None:
+        assert len(all_lengths) == world * n, "all_lengths must cover every (padded) slot of every rank"
+        all_len = [int(v) for v in all_lengths]
+    else:
+        lens = torch.tensor([t.shape[0] for t in local], dtype=torch.int64).to(dev)
+        all_len = torch.empty(world * n, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(all_len, lens, group=group)
+        all_len = all_len.cpu().tolist()         # host synchronisation: pass all_lengths to avoid it
     return [all_buf[i, : all_len[i]] for i in range(world * n)]
 
 
 def run_sharded(infer_fn, audios: Sequence[torch.Tensor], styles=None, gather: bool = True, group=None,
-                max_frames: Optional[int] = None, force_collective: bool = False):
+                max_frames: Optional[int] = None, force_collective: bool = False, lengths: Optional[Sequence[int]] = None):
     """Shard ``audios`` over the ranks, run ``infer_fn(list_of_audio, list_of_style)`` on the local shard and
     (optionally) all-gather.  Result order equals input order; shards are padded to equal size with empties.
-    ``audios`` only needs ``len()`` and indexing (a lazy sequence may build just the local clips); pass ``max_frames``
-    (frames of the longest clip of ALL ranks) in that case, otherwise it is derived from every clip's length."""
+    ``audios`` only needs ``len()`` and indexing (a lazy sequence may build just the local clips); pass ``lengths`` (frames of
+    EVERY clip of the job, e.g. ``seq_length(n_samples)``) or at least ``max_frames`` in that case.  With ``lengths`` - given, or
+    derived here from every clip's sample count when neither is given - the gather is one collective and the host never waits
+    for the device (``gather_clips``); with only ``max_frames`` the lengths are exchanged and read back."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = len(audios)
@@ -92,9 +104,19 @@ def run_sharded(infer_fn, audios: Sequence[torch.Tensor], styles=None, gather: b
     else:
         dev = torch.device("cpu")
     padded = list(out) + [torch.zeros(0, D, device=dev)] * (per - len(out))
-    if max_frames is None:
-        max_frames = max(seq_length(int(audios[i].shape[-1])) for i in range(n))
-    allc = gather_clips(padded, max_frames, group, force_collective)
+    if lengths is None and max_frames is None:
+        lengths = [seq_length(int(audios[i].shape[-1])) for i in range(n)]
+    if lengths is not None:
+        assert len(lengths) == n
+        if max_frames is None:
+            max_frames = max(lengths)
+    slots = None
+    if lengths is not None:      # frames of every padded slot, rank-major (empty slots pad the shorter shards)
+        slots = []
+        for r in range(world):
+            rr = shard_range(n, r, world)
+            slots += [int(lengths[i]) for i in rr] + [0] * (per - len(rr))
+    allc = gather_clips(padded, max_frames, group, force_collective, slots)
     res = []
     for r in range(world):
         k = len(shard_range(n, r, world))

@@ -12,7 +12,6 @@ PyTorch is used for device memory and streams only; all arithmetic runs in ``lib
 from __future__ import annotations
 
 import ctypes as C
-import os
 import math
 from typing import List, Optional, Sequence
 
@@ -237,6 +236,14 @@ class BitwiseARModel:
         return dict(zip(keys, list(out)))
 
     # ------------------------------------------------------------------ style-clip cache
+    def _style_key(self, s: torch.Tensor):
+        """Cache key of a style clip.  A host tensor is keyed by its CONTENT (a hash of its 21 KB: a numpy alias or a ``.data``
+        write changes the values without touching ``_version``, and the reference recomputes the condition on every call,
+        app/models.py:67-73); a device tensor by identity, version counter and layout (reading it back would synchronise)."""
+        if not s.is_cuda:
+            return ("host", hash(s.detach().to(torch.float32).contiguous().numpy().tobytes()), self._precision)
+        return ("dev", s.data_ptr(), s._version, tuple(s.stride()), s.dtype, str(s.device), self._precision)
+
     def _style_rows(self, style_motions, order, B):
         """(style_t [B,50,106] or None, has [B] or None) for artalk_infer / artalk_stream_begin.  A style clip seen before is
         passed as its cached 768-float condition (flag 2: the style encoder is skipped for it); new clips go in as clips (flag 1)
@@ -254,7 +261,7 @@ class BitwiseARModel:
                 continue
             assert tuple(s.shape) == (L, D), f"Invalid style_motion shape: {tuple(s.shape)}."
             if self.style_cache_size > 0:
-                keys[pos] = (s.data_ptr(), s._version, str(s.device), self._precision)
+                keys[pos] = self._style_key(s)
             else:
                 style_t[pos] = s.to(device=dev, dtype=torch.float32)
                 has[pos] = 1
@@ -428,14 +435,13 @@ class BitwiseARModel:
             # Host clips are staged on a stream of their own: nothing orders their H2D copies behind the previous call's kernels, so in a
             # serving loop the upload of batch i+1 runs under the compute of batch i.  Device inputs keep the caller's stream order.
             on_host = all(not a.is_cuda for a in audios) if not packed else not audios.is_cuda
-            if os.environ.get("ARTALK_H2D_STREAM", "1") == "0":      # tuning: uploads in the caller's stream order
-                on_host = False
             if self._h2d_stream is None:
                 self._h2d_stream = torch.cuda.Stream(device=dev)
             stage = self._h2d_stream if on_host else caller
             with torch.cuda.stream(stage):
                 if packed and n_samples[0] == maxch * spc:
-                    audio_pad = audios.to(device=dev, dtype=torch.float32, non_blocking=True)      # already whole chunks
+                    # already whole chunks; .contiguous(): artalk_infer reads rows densely (a transposed / sliced view is copied)
+                    audio_pad = audios.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
                 else:
                     audio_pad = torch.zeros(B, maxch * spc, dtype=torch.float32, device=dev)   # zero padding of app/models.py:81-85
                     if packed:

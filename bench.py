@@ -192,6 +192,7 @@ def main():
             return self.rows[i]
 
     clips = ClipList()
+    all_frames = [frames_per_clip] * len(clips)
     mine = adist.shard_range(len(clips), rank, world)
     host_audio = [clips[i] for i in mine]                                         # pinned host memory
     dev_audio = [a.to(dev) for a in host_audio]                                   # the same clips resident in HBM (--resident)
@@ -206,7 +207,8 @@ def main():
     # batches in flight: batch i+1 is enqueued (its upload runs on its own stream under the kernels of batch i) before the host waits for
     # batch i's health flags and download; --synchronous waits for every batch before it enqueues the next (reported as `synchronous`).
     def submit():
-        outs = adist.run_sharded(infer_fn, clips, None, gather=collective, max_frames=frames_per_clip, force_collective=args.force_collective)
+        outs = adist.run_sharded(infer_fn, clips, None, gather=collective, max_frames=frames_per_clip, force_collective=args.force_collective,
+                                 lengths=all_frames)      # lengths known on the host: one collective, no read-back, batches stay in flight
         ticket = model.last_ticket()
         local = outs[mine.start:mine.stop] if collective else outs
         ev = None
@@ -283,9 +285,42 @@ def main():
                 if int(g["style_seed"][i]) < 0 and int(g["seed"][i]) < B:         # the bench runs unstyled clips
                     errs[int(g["seed"][i])] = float(np.abs(res[int(g["seed"][i])] - g["out"][f0:f0 + nf]).max())
                 f0 += nf
+            # Parity of the benchmarked batch, as the GPU tests define it (tests/conftest.py::assert_clip_parity): one extra, untimed call
+            # returns the bits as well (deterministic: its codes must equal the timed run's bit for bit); every AR / history decision
+            # group in causal order against the reference's, FLAME codes within 1e-3 over the whole clip.  A clip whose FIRST difference
+            # is a sign decision at a reference margin below the rounding-level thresholds is counted in rounding_level_clips and held
+            # to the continuation the pinned CPU oracle gives with that decision inverted; any other difference fails the run.
+            sys.path.insert(0, os.path.join(REPO, "tests"))
+            sys.path.insert(0, os.path.join(REPO, "oracle"))
+            from conftest import assert_clip_parity, load_clip_set
+            gclips = load_clip_set("full_cfg2_synth8")
+            aux_out = model.inference_batch(dev_audio, None, return_aux=True)
+            rounding, exact_chunks, worst = 0, 0, 0.0
+            for c in gclips:
+                if c["style_seed"] >= 0 or c["seed"] >= B:
+                    continue
+                i = c["seed"]
+                o_i = aux_out[i].cpu().numpy()
+                if not np.array_equal(o_i, res[i]):
+                    log(f"PARITY FAILURE: clip {i}: the untimed parity call differs from the timed run (the path must be deterministic)")
+                    rc = 3
+                try:
+                    good, n, err = assert_clip_parity(f"bench clip {i}", args.precision, o_i, model.last_aux["bits"][i].cpu().numpy(),
+                                                      model.last_aux["hist_bits"][i].cpu().numpy(), c["out"], c["bits"], c["hist_bits"],
+                                                      c["logit_margin"], c["hist_margin"], inputs=("full", host_audio[i].clone(), None))
+                    exact_chunks += good
+                    worst = max(worst, err)
+                    rounding += 1 if assert_clip_parity.last_rounding_level else 0
+                except AssertionError as e:
+                    log(f"PARITY FAILURE: {e}")
+                    rc = 3
             parity = {"fixture": "tests/golden/full_cfg2_synth8.npz (reference outputs)", "clips": sorted(errs),
-                      "flame_max_abs_err": max(errs.values()), "tolerance": 1e-3}
-            if not parity["flame_max_abs_err"] < 1e-3:
+                      "flame_max_abs_err": worst if rounding else max(errs.values()), "tolerance": 1e-3,
+                      "decision_exact_chunks": exact_chunks, "rounding_level_clips": rounding,
+                      "rounding_level_note": ("clips of THIS batch whose first difference from the reference is a sign decision at a reference "
+                                              "margin below 2e-5 (logit) / 2e-6 (history), held to the oracle's forced-decision continuation; "
+                                              "the counts over all 50 reference goldens are printed by tests/test_configs_gpu.py and tests/test_e2e_gpu.py")}
+            if not rounding and not parity["flame_max_abs_err"] < 1e-3:
                 log(f"PARITY FAILURE: {errs}")
                 rc = 3
 
@@ -364,6 +399,47 @@ def main():
         result["f32_mode"] = {"value": round(B * frames_per_clip / dt32, 1), "ms_per_step": round(dt32 * 1e3, 2),
                               "roofline": {"bound": "mfma", "achieved": round(tf32, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                            "frac": round(tf32 / PEAK_F32_MFMA_TFLOPS, 4), "kernel": MODES["f32"][2]}}
+
+    if extras:
+        # latency figures outside the headline region: BASELINE configs[1] (ONE 10 s clip end to end as the reference runs it, app/models.py:62-121:
+        # pinned host audio -> codes in pinned host memory) and the streaming call (artalk_stream_chunk, app/models.py:92-114: one 4-s block per
+        # stream, host chunk in, host codes out), median over repeated calls after a warm-up that captures the graphs of those batch sizes
+        import statistics
+
+        def median_ms(fn, n):
+            ts = []
+            for _ in range(n):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                fn()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            return round(statistics.median(ts), 3)
+
+        one_host = torch.empty(frames_per_clip, cfg.motion_dim).pin_memory()
+
+        def one_clip():
+            one_host.copy_(model.inference_batch([host_audio[0]])[0], non_blocking=False)
+
+        for _ in range(2):
+            one_clip()
+        result["batch1_latency_ms"] = {"value": median_ms(one_clip, 12), "workload": f"configs[1]: batch=1, one synthetic {args.seconds:g} s clip, "
+                                       "H2D + path + D2H, median of 12 synchronous calls", "precision": args.precision}
+        spc = cfg.samples_per_chunk
+        stream_ms = {}
+        for nb in (1, B):
+            chunk_host = torch.stack([host_audio[i % len(host_audio)][:spc] for i in range(nb)]).pin_memory()
+            out_host = torch.empty(nb, 100, cfg.motion_dim).pin_memory()
+            model.stream_begin(nb)
+
+            def one_chunk():
+                out_host.copy_(model.stream_chunk(chunk_host.to(dev, non_blocking=True)), non_blocking=False)
+
+            for _ in range(2):
+                one_chunk()
+            stream_ms[f"B{nb}"] = median_ms(one_chunk, 12 if nb == 1 else 6)
+            model.stream_end()
+        result["stream_chunk_ms"] = dict(stream_ms, workload="artalk_stream_chunk: one 4-s block (100 frames) per stream, host chunk in -> host codes out, "
+                                         "median of synchronous calls; 4000 ms of audio per call")
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         sys.path.insert(0, os.path.join(REPO, "oracle"))

@@ -183,12 +183,11 @@ int artalk_op_gemm_f16s(const float* A, int64_t lda, const float* W, const float
 int artalk_op_pack_split(const float* in, void* out_u32, int64_t n, int is_weight, void* stream);   /* operand scale: 0 activation, 1 weight */
 int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const void* Wp, const float* bias, float* C, int M, int N,
                                int K, int act, int force_cfg, void* stream);
+/* which production LDS-DMA kernel launch_gemm_p8 picks for an M x N x K product with both operands in P8 and no forced
+ * configuration (what the model path calls): 7 = gemm_p8_256_kernel, 8 = gemm_p8_2wgp_kernel; force_cfg 99 of
+ * artalk_op_gemm_f16s_packed launches exactly that choice */
+int artalk_op_gemm_p8_plan(int M, int N, int K);
 /* y = LN(x)[*w+b][*(1+scale)+shift][act], D in {128,512,768,1024}; act | 0x100 writes y in the P8 split format */
-/* skinny split GEMM of the 1- / 5-token AR scale steps (ar_skinny.hip): C = R + gate * act(in @ W^T + bias), W given in the P8 split
- * format; `in` is either A_p8 (rows in the P8 format) or, with A_p8 NULL, the AdaLN-modulated LayerNorm of the fp32 rows X
- * (scale / shift rows of width K, reference app/transformer.py:35,40).  K in {768, 3072 (A_p8 only)}, N % 16 == 0; act | 0x100: C in P8 */
-int artalk_op_ar_skinny(const void* A_p8, const float* X, const float* scale, const float* shift, float eps, const void* Wp,
-                        const float* bias, const float* gate, const float* R, float* C, int M, int N, int K, int act, void* stream);
 int artalk_op_layernorm(const float* X, float* Y, const float* w, const float* b, const float* scale, const float* shift,
                         int M, int D, float eps, int act, void* stream);
 /* Q,K,V,O: [B][L][H*HD] contiguous; l2norm bit 0 -> q,k normalised, q *= qscale[h]; bit 1 -> the fp16 operand-split kernel of

@@ -266,11 +266,13 @@ class ARTalkOracle:
 
     # ------------------------------------------------------------------ full path
     @torch.no_grad()
-    def inference(self, batch, record=None, force_hist=None):
+    def inference(self, batch, record=None, force_hist=None, force_bits=None):
         """app/models.py:62-121 (with_gtmotion=False).  ``record`` (dict) collects per-chunk internals.  ``force_hist``
-        ({history index: [(token, bit), ...]}) inverts the listed history decisions - used only to derive the continuation of a
-        clip after a rounding-level flip (oracle/make_alt_golden.py); the default is the reference's arithmetic."""
+        ({history index: [(token, bit), ...]}) / ``force_bits`` ({chunk index: [(token, bit), ...]}) invert the listed history / AR
+        decisions - used only to derive the continuation of a clip after a rounding-level flip (oracle/make_alt_golden.py,
+        tests/conftest.py); the default is the reference's arithmetic."""
         force_hist = force_hist or {}
+        force_bits = force_bits or {}
         w, cfg, pn = self.w, self.cfg, self.patch_nums
         audio = batch["audio"]
         B = audio.shape[0]
@@ -313,6 +315,9 @@ class ARTalkOracle:
                 logits = self.ar_head(x, cond)
                 pairs = logits.view(B, L, -1, 2)
                 bits = pairs.argmax(dim=-1)                                                          # :104
+                for (tok, bit) in force_bits.get(len(out), ()):          # (test infrastructure only, see the docstring)
+                    if tok < L:
+                        bits[0, tok, bit] ^= 1
                 if pidx < len(pn) - 1:
                     nxt = self.vqidx_to_ar_vqfeat(pidx, bits)
                     nxt = torch.cat([style_cond, F.linear(nxt, w["vqfeat_embed.weight"], w["vqfeat_embed.bias"])], dim=1)

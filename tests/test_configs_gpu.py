@@ -40,12 +40,17 @@ def test_config4_demo_wavs_batch32_styled(precision):
     # decision inverted (oracle/make_alt_golden.py) - in which (2, token 56, bit 8) has a margin of 4.1e-7 and flips again, hence
     # a chain of two stages.  Every other clip must equal the reference golden outright.
     alts = {5: [load_alt("full_cfg4_demo32_alt5_1"), load_alt("full_cfg4_demo32_alt5_2")]}
-    worst, chunks = 0.0, 0
+    worst, chunks, rounding = 0.0, 0, []
     for i, c in enumerate(clips):
         good, n, err = assert_clip_parity(f"cfg4 clip {i} ({c['kind']}, style {c['style_seed']})", precision, outs[i], bits[i], hist[i],
-                                          c["out"], c["bits"], c["hist_bits"], c["logit_margin"], c["hist_margin"], alt=alts.get(i))
+                                          c["out"], c["bits"], c["hist_bits"], c["logit_margin"], c["hist_margin"], alt=alts.get(i),
+                                          inputs=("full", audios[i], styles[i]))
         worst, chunks = max(worst, err), chunks + good
-    print(f"configs[4] [{precision}]: 32 clips, {chunks} chunks decision-exact, worst FLAME max-abs err {worst:.3e}")
+        if assert_clip_parity.last_rounding_level:
+            rounding.append(i)
+    print(f"configs[4] [{precision}]: 32 clips, {chunks} chunks decision-exact, worst FLAME max-abs err {worst:.3e}; "
+          f"rounding_level_clips = {len(rounding)} {rounding} (first difference from the reference at a sub-threshold margin, "
+          "rest of the clip equal to the forced-decision continuation)")
     assert chunks == sum(c["bits"].shape[0] for c in clips) == 96
 
 
@@ -71,6 +76,30 @@ def test_config4_engine_surface():
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_config0_eng1_clip_length_50(precision):
+    """BASELINE configs[0] literally: demo/eng1.wav, clip_length = 50 through the engine (reference inference.py:47-57; shape_id =
+    mesh only selects the renderer, which is outside the path) against the first 50 rows of the reference's smoothed output."""
+    from artalk_amd.engine import ARTAvatarInferEngine
+    from conftest import golden_inputs
+    cfg, sd = get_state_dict("full")
+    g = load_golden("full_demo_eng1")
+    audio, style = golden_inputs(g, sd)
+    eng = ARTAvatarInferEngine(load_gaga=False, fix_pose=False, clip_length=750, device="cuda", state_dict=sd, config=cfg,
+                               model=get_gpu_model("full"))
+    eng.ARTalk.set_precision(precision)
+    try:
+        if style is not None:       # the reference's CLI always sets a style clip (inference.py:233; synthetic here: the asset is absent)
+            eng.set_style_motion(style)
+        pred = eng.inference(audio, clip_length=50).cpu().numpy()
+    finally:
+        eng.ARTalk.set_precision("f32")
+    assert pred.shape == (50, 106)
+    err = np.abs(pred - g["engine_out"][:50]).max()
+    assert err < FLAME_TOL, f"engine output differs by {err:.3e}"
+    assert np.abs(pred[:, 104:]).max() == 0.0
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
 def test_config2_batch32_synthetic_10s(precision):
     from artalk_amd.synth import synth_audio, synth_style
     clips = load_clip_set("full_cfg2_synth8")
@@ -84,14 +113,16 @@ def test_config2_batch32_synthetic_10s(precision):
     try:
         outs, bits, hist = _run_set(m, audios, styles)
         assert m._precision == precision and m.status() == 0, "the call tripped the range guard and was redone in f32 mode"
-        worst = 0.0
+        worst, rounding = 0.0, []
         for i, c in enumerate(clips):                      # seeds 0..7 against the reference itself
             good, n, err = assert_clip_parity(f"cfg2 clip {i}", precision, outs[i], bits[i], hist[i], c["out"], c["bits"], c["hist_bits"],
-                                              c["logit_margin"], c["hist_margin"])
+                                              c["logit_margin"], c["hist_margin"], inputs=("full", audios[i], styles[i]))
             worst = max(worst, err)
+            if assert_clip_parity.last_rounding_level:
+                rounding.append(i)
         for case, i in (("full_10s_s0", 0), ("full_10s_s1_style", 1)):      # the two single-clip fixtures are the same clips
             g = load_golden(case)
-            assert np.abs(outs[i] - g["out"]).max() < FLAME_TOL
+            assert i in rounding or np.abs(outs[i] - g["out"]).max() < FLAME_TOL
         # clips without a golden: identical decisions and codes to rounding as their batch-1 runs
         for i in (9, 15, 22, 31):
             so, sb, sh = _run_set(m, [audios[i]], [styles[i]])
@@ -102,4 +133,4 @@ def test_config2_batch32_synthetic_10s(precision):
         assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(again, outs))
     finally:
         m.set_precision("f32")
-    print(f"configs[2] [{precision}]: 8 golden clips decision-exact, worst FLAME max-abs err {worst:.3e}")
+    print(f"configs[2] [{precision}]: 8 golden clips decision-exact, worst FLAME max-abs err {worst:.3e}; rounding_level_clips = {len(rounding)} {rounding}")

@@ -70,7 +70,22 @@ def _worker_lazy(rank, world, port, n_clips, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     clips = _LazyClips(n_clips)
-    res = run_sharded(_fake_infer, clips, None, gather=True, max_frames=seq_length(16000 + 640 * (n_clips - 1)))
+    # what bench.py passes: the frame count of every clip of the job, known on the host -> ONE collective and no read-back
+    calls, reads = [], []
+    orig, orig_cpu = dist.all_gather_into_tensor, torch.Tensor.cpu
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    torch.Tensor.cpu = lambda self, *a, **k: (reads.append(1), orig_cpu(self, *a, **k))[1]
+    res = run_sharded(_fake_infer, clips, None, gather=True, lengths=[seq_length(16000 + 640 * i) for i in range(n_clips)])
+    dist.all_gather_into_tensor, torch.Tensor.cpu = orig, orig_cpu
+    if len(calls) != 1 or reads:
+        q.put((rank, False))
+        return
+    # only max_frames known: the lengths are exchanged too and read back (the synchronising fallback)
+    clips2 = _LazyClips(n_clips)
+    res2 = run_sharded(_fake_infer, clips2, None, gather=True, max_frames=seq_length(16000 + 640 * (n_clips - 1)))
+    if not all(torch.equal(a, b) for a, b in zip(res, res2)):
+        q.put((rank, False))
+        return
     want = _fake_infer([torch.full((16000 + 640 * i,), float(i + 1)) for i in range(n_clips)], None)
     ok = len(res) == n_clips and all(torch.equal(r, w) for r, w in zip(res, want))
     ok = ok and sorted(clips.built) == list(shard_range(n_clips, rank, world))       # nothing but the local shard was built
@@ -86,10 +101,10 @@ def _worker_single(rank, world, port, n_clips, q):
     calls = []
     orig = dist.all_gather_into_tensor
     dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
-    res = run_sharded(_fake_infer, audios, None, gather=True, force_collective=True)
+    res = run_sharded(_fake_infer, audios, None, gather=True, force_collective=True)      # lengths derived from the sample counts
     dist.all_gather_into_tensor = orig
     want = _fake_infer(audios, None)
-    ok = len(calls) == 2 and all(torch.equal(r, w) for r, w in zip(res, want))
+    ok = len(calls) == 1 and all(torch.equal(r, w) for r, w in zip(res, want))
     q.put((rank, ok))
     dist.destroy_process_group()
 
@@ -99,7 +114,7 @@ def test_lazy_clip_list_world2():
 
 
 def test_force_collective_single_rank():
-    """bench.py --force-collective: a world-size-1 group still runs the two all-gathers (here on gloo; the -m gpu test runs
+    """bench.py --force-collective: a world-size-1 group still runs the all-gather (here on gloo; the -m gpu test runs
     the same code on RCCL)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -138,3 +153,21 @@ def test_gather_single_process_is_identity():
     clips = [torch.ones(3, 106), torch.zeros(5, 106)]
     out = gather_clips(clips, 5)
     assert all(torch.equal(a, b) for a, b in zip(out, clips))
+
+
+def test_bench_self_launch_relays_children_failure():
+    """``python bench.py --gpus 2`` from a GPU-free parent: the parent must not touch the GPU, start the two ranks through
+    ``torch.distributed.run`` on 127.0.0.1 and relay their return code.  Where there are not two GPUs (this container has none, a
+    one-GPU box has one) the ranks fail at device selection: the parent's exit status must be non-zero and its log must show the
+    launch line - a parent that swallowed the failure, or tried to initialise the GPU itself, would not."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs present: the ranks would run the real benchmark")
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                           "--no-alt-mode"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert proc.returncode != 0
+    assert "torch.distributed.run" in proc.stderr and "--nproc-per-node=2" in proc.stderr and "127.0.0.1" in proc.stderr
+    assert '"metric"' not in proc.stdout

@@ -94,6 +94,98 @@ def test_large_ragged_batch():
         _compare(outs[i].cpu().numpy(), bits[i], audios[i])
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_long_clip_30s_eight_chunks(precision):
+    """The reference's default clip_length is 750 frames = 30 s = 8 chunks (inference.py:19,52): the history hand-over
+    (app/models.py:111-114) runs seven times in one call.  Reduced-depth model against the oracle, every chunk decision-exact."""
+    from artalk_amd.synth import synth_audio
+    audio = torch.from_numpy(synth_audio(77, 30.0))
+    m = get_gpu_model("tiny")
+    assert m.n_chunks(audio.shape[0]) == 8 and m.seq_length(audio.shape[0]) == 750
+    err, n = _check(audio, precision)
+    assert n == 8
+    print(f"30 s clip [{precision}]: 8 chunks decision-exact, FLAME max-abs err {err:.3e}")
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_w2v_group_split_full_width(precision):
+    """More than 96 chunks in one call at the FULL model: run_wav2vec (engine.hip) then walks the chunk list in two groups (96 + 6
+    here) and the second chunk index straddles the group boundary.  34 synthetic 10 s clips; seeds 0..7 against the reference's
+    own outputs (tests/golden/full_cfg2_synth8.npz), every chunk decision-exact."""
+    from artalk_amd.synth import synth_audio, synth_style
+    from conftest import assert_clip_parity, load_clip_set
+    clips = load_clip_set("full_cfg2_synth8")
+    cfg, sd = get_state_dict("full")
+    mean, std = sd["basic_vae.motion_mean"].numpy(), sd["basic_vae.motion_std"].numpy()
+    audios = [torch.from_numpy(synth_audio(s, 10.0)) for s in range(34)]
+    styles = [torch.from_numpy(synth_style(s, mean, std)) if (s % 2 == 1 and s < 8) else None for s in range(34)]
+    m = get_gpu_model("full")
+    assert sum(m.n_chunks(a.shape[0]) for a in audios) == 102
+    m.set_precision(precision)
+    try:
+        outs = m.inference_batch(audios, styles, return_aux=True)
+        assert m._precision == precision and m.status() == 0
+        bits = [b.cpu().numpy() for b in m.last_aux["bits"]]
+        hist = [h.cpu().numpy() for h in m.last_aux["hist_bits"]]
+    finally:
+        m.set_precision("f32")
+    worst = 0.0
+    for i, c in enumerate(clips):
+        good, n, err = assert_clip_parity(f"group split clip {i}", precision, outs[i].cpu().numpy(), bits[i], hist[i], c["out"], c["bits"],
+                                          c["hist_bits"], c["logit_margin"], c["hist_margin"], inputs=("full", audios[i], styles[i]))
+        assert good == n == 3
+        worst = max(worst, err)
+    print(f"102 chunks in one call [{precision}]: 8 golden clips decision-exact, worst FLAME max-abs err {worst:.3e}")
+
+
+def test_packed_batch_non_contiguous_view():
+    """A packed (B, N) device tensor that is a strided view (every other sample of a wider buffer) must be read as the view's
+    values, not as dense memory (the fast path passed only stride(0))."""
+    from artalk_amd.synth import synth_audio
+    m = get_gpu_model("tiny")
+    m.set_precision("f32")
+    clips = [torch.from_numpy(synth_audio(400 + i, 8.0)) for i in range(2)]       # 128000 samples = 2 whole chunks
+    wide = torch.zeros(2, 256000)
+    wide[:, ::2] = torch.stack(clips)
+    wide[:, 1::2] = 7.0                                                            # junk between the samples
+    view = wide.cuda()[:, ::2]
+    assert not view.is_contiguous() and view.shape == (2, 128000)
+    want = m.inference_batch(clips)
+    got = m.inference_batch(view)
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+
+
+def test_bad_style_flag_is_refused_before_anything_is_enqueued():
+    """artalk_infer / artalk_stream_begin validate has_style (0, 1, 2) first: EINVAL, no work queued, and a streaming session that
+    is open stays open and continues exactly."""
+    import ctypes as C
+    from artalk_amd import capi
+    from artalk_amd.synth import synth_audio
+    m = get_gpu_model("tiny")
+    m.set_precision("f32")
+    L = capi.lib()
+    audio = torch.from_numpy(synth_audio(410, 8.0))
+    want = m.inference_batch([audio])[0].cpu()
+    m.stream_begin(1)
+    first = m.stream_chunk(audio[None, :64000].cuda()).cpu()
+    # a batch call with a bad flag in the middle of the session
+    pad = audio[None].cuda().contiguous()
+    out = torch.zeros(1, 200, 106, device="cuda")
+    style = torch.zeros(1, 50, 106, device="cuda")
+    bad = (C.c_uint8 * 1)(3)
+    nch = (C.c_int64 * 1)(2)
+    t0 = m.last_ticket()
+    rc = L.artalk_infer(m._h, capi.ptr(pad), pad.stride(0), nch, 1, capi.ptr(style), C.cast(bad, C.c_void_p), capi.ptr(out), out.stride(0),
+                        None, None, None, C.c_void_p(m._stream.cuda_stream))
+    assert rc == capi.EINVAL and "has_style" in m._err()
+    assert m.last_ticket() == t0                       # no call was published
+    second = m.stream_chunk(audio[None, 64000:].cuda()).cpu()      # the session is still there and continues bit for bit
+    assert torch.equal(torch.cat([first[0], second[0]]), want)
+    m.stream_end()
+    assert L.artalk_stream_begin(m._h, 1, capi.ptr(style), C.cast(bad, C.c_void_p), C.c_void_p(m._stream.cuda_stream)) == capi.EINVAL
+
+
 def test_batches_in_flight_and_per_call_status():
     """A serving loop that enqueues batch i+1 before it looks at batch i (``check=False`` + ``status_of(ticket)``): six different
     batches queued back to back from pinned host memory give exactly what one-at-a-time calls give, every call has its own health

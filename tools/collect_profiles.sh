@@ -36,7 +36,7 @@ cp $O/pmc_traffic.json profiles/${R}_pmc_traffic.json
 timeout -k 10 500 python bench.py --steps 20 --warmup 5 2>$O/bench.err | tail -1 > $O/bench_line.json
 cut -c1-400 $O/bench_line.json
 echo "== gemm microbenchmarks"
-GEMM_GRAPH=0 GEMM_VARIANTS="1:1,2:1,7:1,8:1,99:1" GEMM_ONLY="w2v qkv,w2v out,w2v ff1,w2v ff2,conv1,ada" timeout -k 10 200 python tools/gemm_f16s_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_f16s_bench.log
+GEMM_GRAPH=0 GEMM_VARIANTS="1:1,7:1,8:1,99:1" GEMM_ONLY="w2v qkv,w2v out,w2v ff1,w2v ff2,conv1,ada" timeout -k 10 200 python tools/gemm_f16s_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_f16s_bench.log
 timeout -k 10 100 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > $O/attn_bench.log
 echo "== P8 headroom"
 timeout -k 10 200 python tools/p8_headroom.py $O/p8_headroom.json 2>&1 | grep -v amdgpu.ids | tail -14

@@ -20,8 +20,8 @@ for _M in (16, 32, 80, 160, 400, 800, 1600, 3200):
 # row counts whose 128x128 tile counts are whole multiples of the 512 persistent workgroups (round-quantisation check)
 for _M in (8192, 16384):
     SHAPES += [(f"q{_M} qkv", _M, 3072, 1024), (f"q{_M} out", _M, 1024, 1024), (f"q{_M} ff1", _M, 4096, 1024), (f"q{_M} ff2", _M, 1024, 4096)]
-variants = [(1, 1), (2, 1), (7, 1), (8, 1)]   # (cfg, A packed): 0/1 register-staged 128x128 / 64x64; LDS-DMA kernels: 2 128x128, 6 256x128, 7 256x256,
-                                               # 8 two-workgroup 128x128, 20/21/22 small-grid 64x64 / 128x64 / 128x128; cfg | S << 8 = split-K S (8, 20-22)
+variants = [(1, 1), (7, 1), (8, 1), (99, 1)]   # (cfg, A packed): 0/1 register-staged 128x128 / 64x64; LDS-DMA kernels: 7 256x256, 8 persistent
+                                                # two-workgroup 128x128, 99 the dispatch's own choice; small-grid 64x64: 20 (4 stages), 23 (8), 24 (5); cfg | S << 8 = split-K S (20, 23, 24)
 only = os.environ.get("GEMM_ONLY")
 if only:
     SHAPES = [x for x in SHAPES if x[0] in only.split(",") or any(o.endswith("*") and x[0].startswith(o[:-1]) for o in only.split(","))]
@@ -41,7 +41,6 @@ for name, M, N, K in SHAPES:
     ref = A[:256].double() @ W.double().t() + b.double()
     line = f"{name:12s} M={M:6d} N={N:5d} K={K:4d} "
     for cfg, apk in variants:
-        if 2 <= (cfg & 0xff) < 20 and (cfg & 0xff) not in (2, 3, 5, 8) and M < 3000: continue
         best = 1e9
         n = 3 if M * N * K > 1e11 else (10 if ROT == 1 else ROT)
         a = Ap if apk else A

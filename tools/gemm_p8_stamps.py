@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where a tile of the LDS-DMA split GEMM spends its time: per-workgroup wall-clock stamps (timing build, force_cfg 16).
+"""Where a tile of the LDS-DMA split GEMM spends its time: per-workgroup wall-clock stamps of the 256x256 kernel (timing build, force_cfg 17).
 Prints, per shape: median prologue (entry -> first stage landed), main loop, epilogue, the gap between consecutive
 workgroups on the same CU, and the kernel's span."""
 import ctypes as C, os, sys
@@ -11,8 +11,7 @@ L = capi.lib()
 p = lambda t: C.c_void_p(t.data_ptr())
 SHAPES = [("w2v out", 19200, 1024, 1024), ("w2v ff1", 19200, 4096, 1024), ("w2v ff2", 19200, 1024, 4096), ("K=256", 19200, 1024, 256)]
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-CFG = int(os.environ.get("STAMP_CFG", "16"))      # 16: 128x128 kernel, 17: 256x256 kernel, 18: two-workgroup 128x128 kernel
-T = 256 if CFG == 17 else 128
+CFG, T = 17, 256
 for name, M, N, K in SHAPES:
     A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.03
     Ap = torch.empty(M, K, dtype=torch.int32, device="cuda"); Wp = torch.empty(N, K, dtype=torch.int32, device="cuda")
