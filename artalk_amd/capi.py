@@ -149,7 +149,7 @@ def lib() -> C.CDLL:
     L.artalk_op_pack_split.restype = i32
     L.artalk_op_gemm_f16s_packed.argtypes = [vp, i32, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.artalk_op_gemm_f16s_packed.restype = i32
-    L.artalk_op_gemm_p8_plan.argtypes = [i32, i32, i32]
+    L.artalk_op_gemm_p8_plan.argtypes = [i32, i32, i32, i32]
     L.artalk_op_gemm_p8_plan.restype = i32
     L.artalk_op_gemm_ex.argtypes = [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.artalk_op_gemm_ex.restype = i32

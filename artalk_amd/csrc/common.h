@@ -326,9 +326,12 @@ __device__ __forceinline__ void epilogue_tiles(const GemmArgs& g, const EpiCtx& 
 }
 // Store-only form of epilogue_tile32 for a tile whose bias is already added and that has no gate / residual, every lane valid and
 // the 16-byte path available (the deferred epilogue of gemm_p8_2wgp_kernel): activation, then exactly 4 store instructions.
+// rok = false (a row beyond M in an edge tile): the lane computes along (the half-wave exchange of a P8 result needs every lane) and
+// its stores are masked off - the wave still issues exactly 4 store instructions, which the callers' counted vmcnt waits rely on.
 template <bool GUARD = true>
-__device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* C, int row, int col0, int h, f32x16& v, const f32x4* res = nullptr) {
-    const long crow = map_row(g.cmap, row);
+__device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* C, int row, int col0, int h, f32x16& v, const f32x4* res = nullptr,
+                                                      bool rok = true) {
+    const long crow = rok ? map_row(g.cmap, row) : 0;
     apply_act16(v, g.act);
     if (res) {      // residual of the deferred tile (4 runs of 4 columns, staged through LDS by the persistent kernel)
 #pragma unroll
@@ -356,14 +359,16 @@ __device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* 
             }
             unsigned char* o = reinterpret_cast<unsigned char*>(C + crow * g.ldc + col0 + 16 * qp + 8 * h);
             const u32x4_t hi = {w[0][0], w[0][1], w[1][0], w[1][1]}, lo = {w[0][2], w[0][3], w[1][2], w[1][3]};
-            *reinterpret_cast<u32x4_t*>(o) = hi;
-            *reinterpret_cast<u32x4_t*>(o + 16) = lo;
+            if (rok) {
+                *reinterpret_cast<u32x4_t*>(o) = hi;
+                *reinterpret_cast<u32x4_t*>(o + 16) = lo;
+            }
         }
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-            *reinterpret_cast<f32x4*>(C + crow * g.ldc + col0 + 8 * q + 4 * h) = o;
+            if (rok) *reinterpret_cast<f32x4*>(C + crow * g.ldc + col0 + 8 * q + 4 * h) = o;
         }
     }
 }

@@ -457,7 +457,7 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
         }
     }
     const bool dominant = !m->in_body && g.M > 0 &&
-                          (split ? (g.a_packed ? (gemm_p8_eligible(g) && gemm_p8_variant(g) == 1) : gemm_f16s_config(g) == 0) : gemm_config(g) == 4);
+                          (split ? (g.a_packed ? (gemm_p8_eligible(g) && gemm_p8_variant(g) >= 1) : gemm_f16s_config(g) == 0) : gemm_config(g) == 4);
     size_t i0 = 0, i1 = 0;
     if (m->profiling && dominant) next_event(m, s, &i0);
     if (g.a_packed && !split) { m->err = "internal: P8 activation handed to an fp32 GEMM"; m->sticky_error = true; return false; }
@@ -1613,10 +1613,10 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
     g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act & 0xff; g.force_cfg = force_cfg;
     g.c_p8 = (act >> 8) & 1;      // tuning: bit 8 of `act` = result in the P8 split format (same pitch)
     if ((act >> 9) & 1) { g.R = C; g.ldr = N; }      // tuning: bit 9 = residual read from C (in place, as the encoder's out-projection / FFN-out run)
-    if (force_cfg >= 2) {   // LDS-DMA kernels (both operands in P8): 7 = 256x256 tiles, 8 = persistent 128x128, 17 = 7 with wall-clock stamps
+    if (force_cfg >= 2) {   // LDS-DMA kernels (both operands in P8): 7 / 12 = persistent 256x256 / 320x256 tiles, 8 = persistent 128x128, 13 = non-persistent 256x256 (17: with wall-clock stamps)
         if (!a_packed) return ARTALK_EINVAL;
         g.force_cfg = force_cfg == 99 ? -1 : force_cfg;   // 99: the engine's own choice between the production kernels
-        if (force_cfg == 17) { g.partial = (float*)bias; g.bias = nullptr; }   // timing build: `bias` carries the stamp buffer (8 x u64 per tile)
+        if (force_cfg == 17) { g.partial = (float*)bias; g.bias = nullptr; }     // (17: gemm_p8_256_kernel with stamps)   // timing build: `bias` carries the stamp buffer (8 x u64 per tile)
         if (force_cfg != 99 && (force_cfg & 0xff) >= 20) {     // 20 / 23 / 24: small-grid LDS-DMA kernel; bits 8-15: split-K factor (slabs in a temporary)
             g.force_cfg = force_cfg & 0xff;
             const int S = (force_cfg >> 8) & 0xff;
@@ -1644,10 +1644,12 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }
 
-int artalk_op_gemm_p8_plan(int M, int N, int K) {
+int artalk_op_gemm_p8_plan(int M, int N, int K, int residual) {
     GemmArgs g;
-    g.M = M; g.N = N; g.K = K;
-    return gemm_p8_variant(g) == 1 ? 7 : 8;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
+    if (residual) { g.R = reinterpret_cast<const float*>(16); g.ldr = N; }     // only its presence and alignment are looked at
+    const int v = gemm_p8_variant(g);
+    return v == 1 ? 7 : (v == 2 ? 12 : 8);
 }
 
 int artalk_op_layernorm(const float* X, float* Y, const float* w, const float* b, const float* scale, const float* shift, int M,

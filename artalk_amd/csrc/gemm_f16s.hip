@@ -17,6 +17,7 @@
 // hi halves + 16 bytes of lo halves), so a packed matrix has the same size, pitch and 16-byte loads as the fp32 one and a
 // 16-byte chunk is an MFMA fragment.  LDS rows (register-staged kernel) hold the hi plane (BK halves) followed by the lo
 // plane, padded to 144 bytes (conflict-free ds_read_b128 for the 32x32x16 operand map: lane (r,h) holds k = 8h..8h+7).
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -462,7 +463,7 @@ __device__ __forceinline__ void static_for(F&& f) {
         static_for<U + 1, N>(f);
     }
 }
-template <int TM, int TAG = 0>
+template <int TM, bool RES, int TAG = 0>      // RES: tiles with a residual (g.R != nullptr), a compile-time property so that the epilogue is straight-line code
 __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
     constexpr int BM = 64 * TM, BN = 256, BK = 32;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
@@ -472,17 +473,38 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
 
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
     const int ntiles = tiles_n * tiles_m;
     const int wm = wave >> 2, wn = wave & 3;
-    const int r = lane & 31, h = lane >> 5;
-    const int prow = lane >> 3, pchunk = lane & 7;
     const int nk = g.K / BK;
+    // Everything derived from the lane index (fragment addresses, DMA source offsets) is RE-derived at the phase boundaries of a tile
+    // (derive(): the lane index passes through an empty asm, so nothing computed from the old copy can be reused): the main loop's
+    // address registers are then dead in the epilogue and the epilogue's in the main loop, instead of 30 registers living through both -
+    // with 128 / 160 accumulator registers of 256 that is the difference between no spills and hundreds.
+    int lane = tid & 63, r, h, prow, pchunk;
+    // LDS byte addresses of this lane's hi / lo fragments of k block 0 in ring buffer 0 (the dynamic LDS starts at address 0: rows are
+    // 128-byte aligned); k block 1 is the same address with bit 6 flipped (logical chunk + 4 under the XOR swizzle), ring buffer 1 is
+    // + STAGE_BYTES, further tiles + 4096 B per 32 rows (same swizzle key, an immediate).  Four registers instead of sixteen.
+    unsigned a_off[2], w_off[2];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_p8;
+    auto derive = [&]() __attribute__((always_inline)) {
+        asm volatile("" : "+v"(lane));
+        r = lane & 31; h = lane >> 5; prow = lane >> 3; pchunk = lane & 7;
+        const int arow = wm * (32 * TM) + r, wrow = wn * 64 + r;
+        const int akey = (arow >> 1) & 7, wkey = (wrow >> 1) & 7;
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo) {
+            const int c = h * 2 + lo;
+            a_off[lo] = lds0 + arow * 128 + ((c ^ akey) << 4);
+            w_off[lo] = lds0 + BM * 128 + wrow * 128 + ((c ^ wkey) << 4);
+        }
+    };
+    derive();
 
     // tile index -> origin: XCD-contiguous (workgroups b and b + 8 share an XCD and gridDim.x % 8 == 0, so tile t runs on XCD t & 7),
     // grouped column-major inside groups of 8 row tiles (8 x 4 tiles per XCD at a time)
-    auto tile_origin = [&](int t, int& m0, int& n0) {
+    auto tile_origin = [&](int t, int& m0, int& n0) __attribute__((always_inline)) {
         const int xcd = t & 7, q = ntiles >> 3, rr = ntiles & 7;
         const int idx = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
         constexpr int GM = 8;
@@ -495,81 +517,74 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
         n0 = tn * BN;
     };
 
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_p8;
-    unsigned a_off[2][2], w_off[2][2];               // [kb][hi/lo]; further tiles are +4096 B per 32 rows (same swizzle key)
-    {
-        const int arow = wm * (32 * TM) + r, wrow = wn * 64 + r;
-        const int akey = (arow >> 1) & 7, wkey = (wrow >> 1) & 7;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int lo = 0; lo < 2; ++lo) {
-                const int c = (kb * 2 + h) * 2 + lo;
-                a_off[kb][lo] = lds0 + arow * 128 + ((c ^ akey) << 4);
-                w_off[kb][lo] = lds0 + BM * 128 + wrow * 128 + ((c ^ wkey) << 4);
-            }
-    }
-
-    const unsigned char* src[NDMA];
-    const float* bias_src = nullptr;
-    auto set_src = [&](int m0, int n0) {
-#pragma unroll
-        for (int q = 0; q < TM; ++q) {
-            const int ra = (wave * TM + q) * 8 + prow;                  // tile row of this lane in piece q
-            const int gm = min(m0 + ra, g.M - 1);                       // clamp: rows >= M are never stored
-            src[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda) * 4 + ((pchunk ^ ((ra >> 1) & 7)) << 4);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int rw = (wave * 4 + q) * 8 + prow;
-            const int gn = min(n0 + rw, g.N - 1);
-            src[TM + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw) * 4 + ((pchunk ^ ((rw >> 1) & 7)) << 4);
-        }
-        // this wave's 64 bias values, one float per lane (an address that is always valid when there is no bias: the slot is then unused)
-        bias_src = g.bias ? g.bias + min(n0 + wn * 64 + lane, g.N - 1) : reinterpret_cast<const float*>(g.Wp) + lane;
+    // DMA source addressing: piece q of a wave covers tile rows (wave * TM + q) * 8 + prow (A) / (wave * 4 + q) * 8 + prow (W); lane =
+    // (row in piece, physical 16-byte chunk).  Only the offset of the lane's row in piece 0 and its swizzle term are kept in registers
+    // (32-bit byte offsets from the operand bases: the launcher takes this kernel only for operands below 4 GiB); a piece's offset is
+    // min(row0 + q * 8 rows, last row) + swizzle, three VALU instructions at issue time - nine stored offsets were what pushed the
+    // 320-row tile into spilling.  Swizzle: chunk ^ ((row >> 1) & 7) with row = 8 * piece + prow, i.e. (piece & 1) * 4 + (prow >> 1).
+    unsigned a_row0 = 0, w_row0 = 0, swz = 0;        // byte offsets of the lane's row of piece 0; (pchunk ^ (prow >> 1)) << 4
+    unsigned a_last = 0, w_last = 0;                 // (wave-uniform) offsets of the operands' last rows: the clamp of edge tiles
+    const unsigned a_step = (unsigned)(8 * g.lda * 4), w_step = (unsigned)(8 * g.ldw * 4);
+    const unsigned char* const Abase = reinterpret_cast<const unsigned char*>(g.A);
+    const unsigned char* const Wbase = reinterpret_cast<const unsigned char*>(g.Wp);
+    const unsigned char* const Bbase = g.bias ? reinterpret_cast<const unsigned char*>(g.bias) : reinterpret_cast<const unsigned char*>(g.Wp);
+    int bias_col0 = 0;                               // (wave-uniform) first bias column of this wave for the tile `src` points at
+    auto set_src = [&](int m0, int n0) __attribute__((always_inline)) {
+        a_row0 = (unsigned)(m0 + wave * TM * 8 + prow) * (unsigned)(g.lda * 4);
+        w_row0 = (unsigned)(n0 + wave * 32 + prow) * (unsigned)(g.ldw * 4);
+        a_last = (unsigned)(g.M - 1) * (unsigned)(g.lda * 4);
+        w_last = (unsigned)(g.N - 1) * (unsigned)(g.ldw * 4);
+        swz = (unsigned)((pchunk ^ (prow >> 1)) << 4);
+        bias_col0 = n0 + wn * 64;
     };
-    auto issue_piece = [&](int q, int kt, int buf) {
+    auto issue_piece = [&](int q, int kt, int buf) __attribute__((always_inline)) {
         unsigned char* dst = smem_p8 + buf * STAGE_BYTES + (q < TM ? (wave * TM + q) * 1024 : BM * 128 + (wave * 4 + q - TM) * 1024);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (long)kt * (BK * 4)),
+        const int p = q < TM ? wave * TM + q : wave * 4 + q - TM;             // piece index inside the operand's tile (wave-uniform)
+        const unsigned off = (q < TM ? min(a_row0 + (unsigned)q * a_step, a_last) : min(w_row0 + (unsigned)(q - TM) * w_step, w_last)) +
+                             (swz ^ (unsigned)((p & 1) << 6));
+        const unsigned char* base = (q < TM ? Abase : Wbase) + (long)kt * (BK * 4);      // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
-    auto issue_bias = [&](int slot) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bias_src,
+    auto issue_bias = [&](int slot) __attribute__((always_inline)) {
+        // this wave's 64 bias values, one float per lane (without a bias: any valid address, the slot is then unused)
+        const unsigned off = g.bias ? (unsigned)min(bias_col0 + lane, g.N - 1) * 4u : (unsigned)lane * 4u;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bbase + off),
                                          (__attribute__((address_space(3))) void*)(smem_p8 + BIAS_OFF + slot * 2048 + wave * 256), 4, 0, 0);
     };
 
     f32x16 acc[TM][2];
     f16x8 bh[2][2], bl[2][2];      // [k block][n tile]
     f16x8 ah[2], al[2];            // two slots, sub-step u lives in slot u & 1
-    auto read_b = [&](unsigned sb, int kb) {
-        bh[kb][0] = lds_read128<0>(w_off[kb][0] + sb);
-        bl[kb][0] = lds_read128<0>(w_off[kb][1] + sb);
-        bh[kb][1] = lds_read128<4096>(w_off[kb][0] + sb);
-        bl[kb][1] = lds_read128<4096>(w_off[kb][1] + sb);
+    auto read_b = [&](unsigned sb, int kb) __attribute__((always_inline)) {
+        const unsigned hp = (w_off[0] + sb) ^ (kb << 6), lp = (w_off[1] + sb) ^ (kb << 6);
+        bh[kb][0] = lds_read128<0>(hp);
+        bl[kb][0] = lds_read128<0>(lp);
+        bh[kb][1] = lds_read128<4096>(hp);
+        bl[kb][1] = lds_read128<4096>(lp);
     };
-    // One K step out of ring buffer `buf`.  ISSUE: the pieces of K tile kt_issue of the tile `src` points at go into the other buffer
-    // meanwhile, one per two MFMAs.  pre: vector-memory instructions that may stay in flight at the top (everything OLDER than them
+    // One K step out of ring buffer `buf`.  ISSUE (wave-uniform, a scalar branch per piece: ONE copy of the step's code serves every
+    // step of the kernel): the pieces of K tile kt_issue of the tile `src` points at go into the other buffer meanwhile, one per two MFMAs.  pre: vector-memory instructions that may stay in flight at the top (everything OLDER than them
     // - in particular this step's stage - has landed).
-    auto kstep = [&](int buf, auto issue_tag, int kt_issue, int pre) {
-        constexpr bool ISSUE = decltype(issue_tag)::value;
+    auto kstep = [&](int buf, bool ISSUE, int kt_issue, int pre) __attribute__((always_inline)) {
         const unsigned sb = buf * STAGE_BYTES;
-        if (pre <= 0) wait_vmcnt<0>();
-        else if (pre == NDMA) wait_vmcnt<NDMA>();
-        else if (pre == 8 * TM) wait_vmcnt<8 * TM>();
-        else if (pre == 8 * TM + NDMA) wait_vmcnt<8 * TM + NDMA>();
+        if (pre == 16) wait_vmcnt<16>();                                  // later tiles with a residual: the last few sub-tiles' stores
+        else if (pre == 1 + NDMA) wait_vmcnt<1 + NDMA>();                 // first tile, step 0: bias piece + stage 1
+        else if (pre == 8 * TM) wait_vmcnt<8 * TM>();                     // later tiles, step 1: the previous tile's stores
+        else if (pre == 8 * TM + 1 + NDMA) wait_vmcnt<8 * TM + 1 + NDMA>();   // later tiles, step 0: bias piece + stage 1 + stores
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         read_b(sb, 0);
-        ah[0] = lds_read128<0>(a_off[0][0] + sb);
-        al[0] = lds_read128<0>(a_off[0][1] + sb);
-        static_for<0, NSUB>([&](auto u_tag) {
+        ah[0] = lds_read128<0>(a_off[0] + sb);
+        al[0] = lds_read128<0>(a_off[1] + sb);
+        static_for<0, NSUB>([&](auto u_tag) __attribute__((always_inline)) {
             constexpr int u = decltype(u_tag)::value, kb = u / TM, i = u % TM, sl = u & 1;
             if constexpr (u + 1 < NSUB) {       // prefetch the next sub-step's fragments, then wait for everything older than them
                 constexpr int nkb = (u + 1) / TM, ni = (u + 1) % TM, nsl = (u + 1) & 1;
                 if constexpr (ni == 0) read_b(sb, nkb);
-                ah[nsl] = lds_read128<ni * 4096>(a_off[nkb][0] + sb);
-                al[nsl] = lds_read128<ni * 4096>(a_off[nkb][1] + sb);
+                ah[nsl] = lds_read128<ni * 4096>((a_off[0] + sb) ^ (nkb << 6));
+                al[nsl] = lds_read128<ni * 4096>((a_off[1] + sb) ^ (nkb << 6));
                 if constexpr (ni == 0) wait_lgkmcnt<6>(); else wait_lgkmcnt<2>();
             } else {
                 wait_lgkmcnt<0>();
@@ -608,6 +623,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
     int pre0 = 1 + (nk > 1 ? NDMA : 0), pre1 = 0;
     int gs = 0, tile_no = 0;        // ring parity (K steps run so far), bias slot parity
     while (true) {
+        if (tile_no > 0) { derive(); set_src(m0, n0); }      // (see derive(): the epilogue's registers end here)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -615,30 +631,29 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         const int t_next = t + gridDim.x;
+#ifdef BIG_NO_NEXT
+        const bool has_next = false;
+#else
         const bool has_next = t_next < ntiles;
+#endif
         int nm0 = 0, nn0 = 0;
         if (has_next) tile_origin(t_next, nm0, nn0);
-        // K steps 0 .. nk-2 fetch K tiles 2 .. nk-1, 0' (stages 0 and 1 of a tile are in the ring when it starts; step kt fetches K tile
-        // kt + 2 into the buffer step kt - 1 ... no: into the buffer of step kt + 1?  The ring has TWO buffers: step kt reads buffer
-        // (gs & 1); the buffer of step kt + 1 was filled during step kt - 1 (or before the tile started); so step kt fetches K tile kt + 1
-        // ONLY if it has not been fetched yet: K tile 1 was fetched up front, hence step 0 issues nothing and step kt >= 1 fetches kt + 1.
-        for (int kt = 0; kt + 1 < nk; ++kt) {
-            const int pre = kt == 0 ? pre0 : (kt == 1 ? pre1 : 0);
-            if (kt == 0) kstep(gs & 1, std::false_type{}, 0, pre);
-            else kstep(gs & 1, std::true_type{}, kt + 1, pre);
+        // Stages 0 and 1 of a tile are in the ring when it starts.  Step kt reads buffer gs & 1 and fetches K tile kt + 1 into the
+        // other one - except step 0, whose K tile 1 is there already (K tile 2 would need the buffer step 0 itself reads).  The last
+        // step runs the ring on into the next tile: its stage 0 goes into the buffer of the step before.
+#pragma nounroll
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool last = kt + 1 == nk;
+            if (last && has_next) set_src(nm0, nn0);
+            const int pre = kt == 0 ? (nk > 1 ? pre0 : 0) : (kt == 1 ? pre1 : 0);      // (nk == 1: stage 0 only, waited for in full)
+            kstep(gs & 1, last ? has_next : kt >= 1, last ? 0 : kt + 1, pre);
             ++gs;
         }
-        // last K step: the ring runs on into the next tile (its stage 0 goes into the buffer of the step before this one)
-        {
-            const int pre = nk == 1 ? pre0 : (nk == 2 ? pre1 : 0);
-            if (has_next) { set_src(nm0, nn0); kstep(gs & 1, std::true_type{}, 0, pre); issue_bias((tile_no + 1) & 1); }
-            else kstep(gs & 1, std::false_type{}, 0, pre);
-            ++gs;
-        }
+        if (has_next) issue_bias((tile_no + 1) & 1);
         // stage 1 of the next tile into the buffer the last step has just read (every wave is done with it after this barrier)
         int behind = 0;                 // vector-memory instructions issued behind the next tile's stage 0
         if (has_next) {
-            behind = 1;                 // the bias piece
+            behind = 1;                 // the bias piece (above)
             if (nk > 1) {
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -648,37 +663,60 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
                 behind += NDMA;
             }
         }
-        // ---- epilogue of tile (m0, n0) ----
-        const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
-        const bool full = m0 + BM <= g.M && n0 + BN <= g.N;
+        // ---- epilogue of tile (m0, n0): bias from this wave's LDS slot (written by its own DMA, which came with the tile's stage 0 and is
+        // older than everything waited for since), activation, exactly 4 store instructions per sub-tile (rows beyond M masked).  The
+        // launcher guarantees the 16-byte path (make_epi's test), no gate and N % 256 == 0. ----
+        derive();       // the main loop's address registers end here
         const unsigned char* bslot = smem_p8 + BIAS_OFF + (tile_no & 1) * 2048 + wave * 256;
-        int stores = -1;                // store instructions issued by the fast path (-1: unknown, drain)
-        if (epi.vec && !g.R && !g.gate && full) {
-            // fast path: bias from LDS, activation, exactly 4 store instructions per sub-tile, no loads.  The bias slot was written by
-            // this wave's own DMA, which is older than everything waited for since (it came with the tile's stage 0).
-            f32x16* a = &acc[0][0];
-#pragma nounroll
-            for (int st = 0; st < NSUB; ++st) {      // ONE copy of the code: the sub-tile to finish is always acc[0][0]
-                const int i = st >> 1, j = st & 1;
+        constexpr bool has_res = RES;      // (never together with an activation or a P8 result: p8_big_ok)
+        auto finish = [&](auto i_tag, auto j_tag, const f32x4 (&res)[4]) __attribute__((always_inline)) {      // sub-tile (i, j)
+            constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value;
+            const int row = m0 + wm * (32 * TM) + i * 32 + r;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                    if (g.bias) b = *reinterpret_cast<const f32x4*>(bslot + (j * 32 + 8 * q + 4 * h) * 4);
+            for (int q = 0; q < 4; ++q) {
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (g.bias) b = *reinterpret_cast<const f32x4*>(bslot + (j * 32 + 8 * q + 4 * h) * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a[0][4 * q + e] = a[0][4 * q + e] * kOutScale + b[e];
-                }
-                epilogue_tile32_store<false>(g, g.C, m0 + wm * (32 * TM) + i * 32 + r, n0 + wn * 64 + j * 32, h, a[0]);
-#pragma unroll
-                for (int u = 0; u + 1 < NSUB; ++u) a[u] = a[u + 1];
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = acc[i][j][4 * q + e] * kOutScale + b[e];
             }
-            stores = 4 * NSUB;
-        } else {
-            epilogue_tiles<true, false, TM, 2>(g, epi, m0 + wm * (32 * TM) + r, n0 + wn * 64, h, acc, kOutScale);
-        }
+            if constexpr (has_res) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += res[q][e];
+            }
+            epilogue_tile32_store<false>(g, g.C, row, n0 + wn * 64 + j * 32, h, acc[i][j], nullptr, row < g.M);
+        };
+        using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+        // Residual tiles (the encoder's out-projection and FFN-out, x += ... in place; fp32 result): the residual runs of sub-tile s + 1
+        // are requested before sub-tile s is stored (vmcnt counts loads and stores in issue order: requested after the store, they would
+        // wait for it).  The sub-tiles are spelled out (no loop): in straight-line code hipcc counts its waits exactly - the one in front
+        // of sub-tile s leaves the 4 stores of s - 1 and the 4 loads of s + 1 in flight (vmcnt(8) in the disassembly) - while at a loop
+        // back-edge it falls back to vmcnt(0) and drains the stores every time (and raw asm loads are no way out: the compiler takes
+        // their results for complete and may recycle the destination registers while the data is still on its way).
+        f32x4 r0[4], r1[4];
+        auto load_res = [&](f32x4 (&dst)[4], int i, int j) __attribute__((always_inline)) {
+            const int row = min(m0 + wm * (32 * TM) + i * 32 + r, g.M - 1);          // (rows beyond M: any valid address, the stores are masked)
+            const float* rp = g.R + (long)map_row(g.cmap, row) * g.ldr + n0 + wn * 64 + j * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const f32x4*>(rp + 8 * q);
+        };
+        if constexpr (has_res) load_res(r0, 0, 0);
+        static_for<0, TM>([&](auto i_tag) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_tag)::value;
+            if constexpr (has_res) load_res(r1, i, 1);
+            finish(i_tag, J0{}, r0);
+            if constexpr (has_res && i + 1 < TM) load_res(r0, i + 1, 0);
+            finish(i_tag, J1{}, r1);
+        });
+        // vector-memory instructions of this epilogue that may still be in flight when the next tile starts: all its stores.  With a
+        // residual every load of the epilogue has been waited for, and with it everything older - the next tile's stage 0, stage 1
+        // and bias piece included; what is left are the stores behind the last load (at most three sub-tiles'), which 16 covers.
+        const int stores = has_res ? 16 : 4 * NSUB;
+        if (has_res) behind = 0;
         if (!has_next) break;
         // the next tile's K step 0 needs its stage 0: everything issued behind it may stay in flight if it can be counted
-        if (stores >= 0) { pre0 = behind + stores; pre1 = stores; }
-        else { pre0 = 0; pre1 = 0; }
+        pre0 = behind + stores; pre1 = stores;
         t = t_next; m0 = nm0; n0 = nn0; ++tile_no;
     }
 }
@@ -1364,11 +1402,51 @@ void gemm_p8_prepare() {      // more than the default 64 KB of dynamic LDS (out
     if (dev < 0 || dev >= 64 || done[dev]) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_2wgp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128 + 16384);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_2wgp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128 + 16384);
+    const void* big4[] = {reinterpret_cast<const void*>(&gemm_p8_big_kernel<4, false, 0>), reinterpret_cast<const void*>(&gemm_p8_big_kernel<4, false, 1>),
+                          reinterpret_cast<const void*>(&gemm_p8_big_kernel<4, true, 0>), reinterpret_cast<const void*>(&gemm_p8_big_kernel<4, true, 1>)};
+    const void* big5[] = {reinterpret_cast<const void*>(&gemm_p8_big_kernel<5, false, 0>), reinterpret_cast<const void*>(&gemm_p8_big_kernel<5, false, 1>),
+                          reinterpret_cast<const void*>(&gemm_p8_big_kernel<5, true, 0>), reinterpret_cast<const void*>(&gemm_p8_big_kernel<5, true, 1>)};
+    for (const void* f : big4) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096);
+    for (const void* f : big5) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 576 * 128 + 4096);
     done[dev] = true;
 }
-// The two production kernels: force_cfg 7 = gemm_p8_256_kernel (256x256 tiles), 8 = gemm_p8_2wgp_kernel (persistent 128x128, two
-// workgroups per CU, deferred epilogue), -1 = gemm_p8_variant()'s choice; 17 = the 256x256 kernel with wall-clock stamps
-// (tools/gemm_p8_stamps.py).  Needs the 16-byte epilogue path (epi_vec_host) for cfg 8.
+// Production kernels: force_cfg 7 / 12 = gemm_p8_big_kernel with 256 x 256 / 320 x 256 tiles (persistent, one workgroup per CU),
+// 8 = gemm_p8_2wgp_kernel (persistent 128 x 128, two workgroups per CU, deferred epilogue), -1 = gemm_p8_variant()'s choice;
+// 13 = gemm_p8_256_kernel (the non-persistent 256 x 256 kernel, kept as the A/B baseline of the persistent one), 17 = 13 with
+// wall-clock stamps (tools/gemm_p8_stamps.py).  cfg 8 needs the 16-byte epilogue path (epi_vec_host).
+static int gemm_p8_cus() {      // workgroups of the one-per-CU persistent kernel
+    static int n[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return 256;
+    if (!n[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n[dev] = v - v % 8;      // a multiple of 8: tile t then runs on XCD t & 7
+        if (n[dev] <= 0) n[dev] = 8;
+    }
+    return n[dev];
+}
+// what gemm_p8_big_kernel's epilogue and 32-bit source offsets need: whole 256-column tiles, the 16-byte epilogue path, no gate, a
+// residual only with an fp32 result and no activation, no column groups, operands below 4 GiB
+static bool p8_big_ok(const GemmArgs& g) {
+    return g.N % 256 == 0 && g.ngrp == 0 && !g.gate && !(g.R && (g.c_p8 || g.act != ACT_NONE)) && epi_vec_host(g) && (double)g.M * g.lda * 4.0 < 4294967296.0 &&
+           (double)g.N * g.ldw * 4.0 < 4294967296.0;
+}
+template <int TM>
+static void launch_p8_big(const GemmArgs& g, hipStream_t s) {
+    const int tiles = ((g.M + 64 * TM - 1) / (64 * TM)) * ((g.N + 255) / 256);
+    const int cus = gemm_p8_cus();
+    const size_t lds = 2 * (64 * TM + 256) * 128 + 4096;
+    const dim3 grid(tiles < cus ? tiles : cus);
+    if (g.R) {
+        if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_big_kernel<TM, true, 1>), grid, dim3(512), lds, s, g);
+        else hipLaunchKernelGGL((gemm_p8_big_kernel<TM, true, 0>), grid, dim3(512), lds, s, g);
+    } else {
+        if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_big_kernel<TM, false, 1>), grid, dim3(512), lds, s, g);
+        else hipLaunchKernelGGL((gemm_p8_big_kernel<TM, false, 0>), grid, dim3(512), lds, s, g);
+    }
+}
 void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
     if (g0.M <= 0 || g0.N <= 0) return;
     // No range guard in the epilogues of the large-grid kernels (compiled out: epilogue_tile32<.., GUARD = false>; with it the dominant
@@ -1379,9 +1457,16 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
     g.status = nullptr;
     const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t256sq = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     int cfg = g.force_cfg;
-    if (cfg != 7 && cfg != 8 && cfg != 17) cfg = gemm_p8_variant(g) == 1 ? 7 : 8;
-    if (cfg == 8 && !epi_vec_host(g)) cfg = 7;      // (no launch of the path gets here: every large-grid result is 16-byte aligned)
-    if (cfg == 7) {
+    if (cfg != 7 && cfg != 8 && cfg != 12 && cfg != 13 && cfg != 17) {
+        const int v = gemm_p8_variant(g);
+        cfg = v == 1 ? 7 : (v == 2 ? 12 : 8);
+    }
+    if ((cfg == 7 || cfg == 12) && !p8_big_ok(g)) cfg = epi_vec_host(g) ? 8 : 13;      // (tuning / tests only: the dispatch checks p8_big_ok itself)
+    if (cfg == 8 && !epi_vec_host(g)) cfg = 13;     // (no launch of the path gets here: every large-grid result is 16-byte aligned)
+    if (cfg == 7 || cfg == 12) {
+        gemm_p8_prepare();
+        if (cfg == 7) launch_p8_big<4>(g, s); else launch_p8_big<5>(g, s);
+    } else if (cfg == 13) {
         hipLaunchKernelGGL((gemm_p8_256_kernel<0>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g);
     } else if (cfg == 17) {
         hipLaunchKernelGGL((gemm_p8_256_kernel<6>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g);
@@ -1396,15 +1481,26 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), lds, s, g);
     }
 }
-// 0: two-workgroup 128x128 kernel, 1: 256x256 kernel.  The big tile halves the operand bytes per flop (its main loop runs faster)
-// but its 256 KiB epilogue is not overlapped and its grid is four times coarser: it wins from ~3.5 rounds of 256 workgroups on
-// (wav2vec2 q|k|v and FFN-in GEMMs 360 / 384 vs 327 / 342 TF/s, conv1 390 vs 337, AdaLN table 373 vs 316:
-// profiles/r02_gemm_f16s_bench.log; in the model, where those results leave in P8 and through GELU, 1.0 ms per step) and loses on
-// the 300-tile out-projection / FFN-out GEMMs (266 / 305 vs 311 / 338).
+// 0: persistent two-workgroup 128x128 kernel, 1 / 2: persistent big-tile kernel with 256x256 / 320x256 tiles.  A cost model picks the
+// configuration with the shortest critical path: rounds x (K steps x time per step + epilogue), calibrated on the encoder shapes of
+// batch 32 (profiles/r03_gemm_f16s_bench.log): a 64-row slab of a 256-column tile takes 0.58 us per 32-deep K step and ~3 us of
+// epilogue, a pair of co-resident 128x128 tiles 1.1 - 1.5 us per K step (1.3 taken).  At M = 19200 this gives 320x256 everywhere: N = 1024 (out-projection,
+// FFN-out) is ONE round of 240 tiles on 256 CUs where the 128x128 kernel's 512 workgroups need 2.34 rounds (FFN-out 482 -> 406 us),
+// q|k|v 2.81 rounds instead of the 256x256 tile's 3.52 (403 -> 328 us).  ARTALK_P8_BIG = 0 / 1 / 2 forces a variant (A/B runs).
 int gemm_p8_variant(const GemmArgs& g) {
-    const long t256sq = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
-    static const long min256 = getenv("ARTALK_P8_256_MIN") ? atol(getenv("ARTALK_P8_256_MIN")) : 800;      // tuning / tests: dispatch threshold
-    return (t256sq >= min256 && g.N % 256 == 0 && g.ngrp == 0) ? 1 : 0;      // column groups: the 128x128 kernel only
+    static const int forced = getenv("ARTALK_P8_BIG") ? atoi(getenv("ARTALK_P8_BIG")) : -1;
+    const bool big_ok = p8_big_ok(g);
+    if (forced >= 0) return big_ok ? forced : 0;
+    if (!big_ok) return 0;
+    const double nk = g.K / 32, cus = gemm_p8_cus();
+    auto big = [&](int TM) {
+        const double tiles = (double)((g.M + 64 * TM - 1) / (64 * TM)) * ((g.N + 255) / 256);
+        return std::ceil(tiles / cus) * (TM * nk * 0.58 + 3.0 * TM + 2.0);
+    };
+    const double t128 = (double)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const double c0 = std::ceil(t128 / (2 * cus)) * (nk * 1.30 + 4.0), c1 = big(4), c2 = big(5);
+    if (c0 < c1 && c0 < c2) return 0;
+    return c1 < c2 ? 1 : 2;
 }
 bool gemm_p8_eligible(const GemmArgs& g) {
     return g.Wp != nullptr && g.a_packed && g.amode == 0 && g.batch == 1 && g.splitk == 1 && g.K % 32 == 0 && (g.lda % 8) == 0 &&

@@ -183,10 +183,10 @@ int artalk_op_gemm_f16s(const float* A, int64_t lda, const float* W, const float
 int artalk_op_pack_split(const float* in, void* out_u32, int64_t n, int is_weight, void* stream);   /* operand scale: 0 activation, 1 weight */
 int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const void* Wp, const float* bias, float* C, int M, int N,
                                int K, int act, int force_cfg, void* stream);
-/* which production LDS-DMA kernel launch_gemm_p8 picks for an M x N x K product with both operands in P8 and no forced
- * configuration (what the model path calls): 7 = gemm_p8_256_kernel, 8 = gemm_p8_2wgp_kernel; force_cfg 99 of
- * artalk_op_gemm_f16s_packed launches exactly that choice */
-int artalk_op_gemm_p8_plan(int M, int N, int K);
+/* which production LDS-DMA kernel launch_gemm_p8 picks for an M x N x K product (dense rows, with or without a residual) with both
+ * operands in P8 and no forced configuration (what the model path calls): 7 / 12 = gemm_p8_big_kernel with 256x256 / 320x256 tiles,
+ * 8 = gemm_p8_2wgp_kernel; force_cfg 99 of artalk_op_gemm_f16s_packed launches exactly that choice */
+int artalk_op_gemm_p8_plan(int M, int N, int K, int residual);
 /* y = LN(x)[*w+b][*(1+scale)+shift][act], D in {128,512,768,1024}; act | 0x100 writes y in the P8 split format */
 int artalk_op_layernorm(const float* X, float* Y, const float* w, const float* b, const float* scale, const float* shift,
                         int M, int D, float eps, int act, void* stream);

@@ -112,11 +112,11 @@ def test_gemm_p8_dma_pipeline_and_producers():
     # LayerNorm -> P8 (flag in the high bits of `act`: see artalk_op_layernorm)
     assert L.artalk_op_layernorm(_p(dX), _p(Ap), _p(dlw), _p(dlb), None, None, M, K, 1e-5, 0x100, None) == 0
     out = torch.full((M, N), float("nan"), device="cuda")
-    # LDS-DMA kernels: 7 = 256x256 tiles, 8 = persistent two-workgroup 128x128 (deferred epilogue), 99 = launch_gemm_p8's own choice
-    # (here: below the 256x256 threshold -> the persistent kernel over one whole round of 512 tiles + 8 more); register-staged 128x128
-    # and 64x64 (0, 1); the small-grid LDS-DMA kernel (20) and its deep-ring split-K configurations (23, 24; cfg | S << 8 = split-K S),
-    # all fed with the P8 activation
-    for cfg in (7, 8, 99, 0, 1, 20, 20 | (3 << 8), 23 | (4 << 8), 24 | (6 << 8)):
+    # LDS-DMA kernels: 7 / 12 = persistent 256x256 / 320x256 tiles (M = 8269 leaves an edge tile of 77 / 269 rows), 13 = the non-persistent
+    # 256x256 kernel, 8 = persistent two-workgroup 128x128 (deferred epilogue), 99 = launch_gemm_p8's own choice; register-staged
+    # 128x128 and 64x64 (0, 1); the small-grid LDS-DMA kernel (20) and its deep-ring split-K configurations (23, 24; cfg | S << 8 =
+    # split-K S), all fed with the P8 activation
+    for cfg in (7, 12, 13, 8, 99, 0, 1, 20, 20 | (3 << 8), 23 | (4 << 8), 24 | (6 << 8)):
         out.fill_(float("nan"))
         assert L.artalk_op_gemm_f16s_packed(_p(Ap), 1, K, _p(Wp), _p(db), _p(out), M, N, K, 0, cfg, None) == 0
         torch.cuda.synchronize()
@@ -132,14 +132,17 @@ def test_gemm_p8_dma_pipeline_and_producers():
             assert err < 2e-6, (Ms, cfg, err)
 
 
-@pytest.mark.parametrize("M,N,K,want", [(19200, 3072, 1024, 7),        # wav2vec2 q|k|v at batch 32: 900 tiles of 256x256 -> the 256x256 kernel
-                                        (8192 + 77, 1024, 1024, 8)])   # 132 such tiles: below the threshold -> the persistent 128x128 kernel
+@pytest.mark.parametrize("M,N,K", [(19200, 3072, 1024),        # wav2vec2 q|k|v at batch 32
+                                   (8192 + 77, 1024, 1024),     # a ragged M, one column round
+                                   (5792, 2048, 1024)])         # AdaLN-table rows (32 x 181), not a multiple of any tile
 @pytest.mark.parametrize("residual", [False, True])
-def test_gemm_p8_auto_dispatch(M, N, K, want, residual):
-    """launch_gemm_p8 with no forced configuration (what the model calls): the plan says which production kernel takes the shape,
-    the result is bit-identical to that kernel forced and correct against float64 - with and without an in-place residual."""
+def test_gemm_p8_auto_dispatch(M, N, K, residual):
+    """launch_gemm_p8 with no forced configuration (what the model calls): the plan says which production kernel takes the shape
+    (a big-tile kernel only without a residual), the result is bit-identical to that kernel forced - and, the accumulation order
+    being the same in every split kernel, to the other production kernels - and correct against float64."""
     capi, L = _lib()
-    assert L.artalk_op_gemm_p8_plan(M, N, K) == want
+    want = L.artalk_op_gemm_p8_plan(M, N, K, int(residual))
+    assert want in (7, 12, 8)
     g = torch.Generator().manual_seed(M + N)
     A = torch.randn(M, K, generator=g)
     W = torch.randn(N, K, generator=g) / math.sqrt(K)
@@ -151,12 +154,13 @@ def test_gemm_p8_auto_dispatch(M, N, K, want, residual):
     assert L.artalk_op_pack_split(_p(dA), _p(Ap), M * K, 0, None) == 0 and L.artalk_op_pack_split(_p(dW), _p(Wp), N * K, 1, None) == 0
     act = 0x200 if residual else 0            # 0x200: residual read from C, in place (as the encoder's out-projection runs)
     outs = []
-    for cfg in (99, want):
+    for cfg in (99, want, 7, 12, 13, 8):
         out = _dev(R.clone()) if residual else torch.full((M, N), float("nan"), device="cuda")
         assert L.artalk_op_gemm_f16s_packed(_p(Ap), 1, K, _p(Wp), _p(db), _p(out), M, N, K, act, cfg, None) == 0
         torch.cuda.synchronize()
         outs.append(out.cpu())
-    assert torch.equal(outs[0], outs[1])
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
     rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)])       # first and last tiles against float64
     ref = A[rows].double() @ W.double().t() + bias.double() + (R[rows].double() if residual else 0.0)
     err = (outs[0][rows].double() - ref).abs().max().item() / ref.abs().max().item()
