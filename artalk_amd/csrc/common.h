@@ -418,7 +418,7 @@ __device__ __forceinline__ void epilogue_row4(const GemmArgs& g, const EpiCtx& x
 }
 // NI x NJ accumulator tiles (C^T layout, already scaled) of one wave = rows row0.. (32 NI) x cols col0.. (32 NJ) -> wave-private LDS
 // (>= 32 NI * (32 NJ + 4) floats, nobody else touches it) -> row-major epilogue, 64/(8 NJ) rows per instruction.
-template <int NI, int NJ>
+template <int NI, int NJ, bool GUARD = false>
 __device__ __forceinline__ void epilogue_wave_lds(const GemmArgs& g, const EpiCtx& x, float* lds, int row0, int col0, int lane,
                                                   f32x16 (&acc)[NI][NJ]) {
     constexpr int COLS = 32 * NJ, PITCH = COLS + 4, LPR = COLS / 4, RPI = 64 / LPR;
@@ -443,7 +443,7 @@ __device__ __forceinline__ void epilogue_wave_lds(const GemmArgs& g, const EpiCt
 #pragma unroll 4
     for (int it = 0; it < 32 * NI / RPI; ++it) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(lds + (it * RPI + rr) * PITCH + cc);
-        epilogue_row4<false>(g, x, row0 + it * RPI + rr, col0 + cc, v, &bpre);      // (only the large-grid kernels come through here)
+        epilogue_row4<GUARD>(g, x, row0 + it * RPI + rr, col0 + cc, v, &bpre);      // (GUARD: the mid-grid kernel of the AR / VAE body; the large-grid kernels leave the range guard to their consumers)
     }
 }
 

@@ -449,6 +449,17 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
             }
             while (S > 1 && (int64_t)S * g.M * g.N > cw.splitk_floats) { --S; cfg = -1; }
             if (S == 5 || S == 7) { --S; }        // the unrolled reduce kernels exist for 2, 3, 4, 6, 8 slabs
+            // Mid-grid kernel (128x128 tiles, one 8-wave workgroup per CU, 4-stage ring: gemm_p8_mid_kernel, cfg 28) where its grid
+            // fills most of the chip: these launches are bound by what an XCD pulls in per K step, and a 128x128 tile has four times
+            // the matrix work per fetched byte of the 64x64 tile (profiles/r03_mid_gemm_sweep.log, cold weights, graph replay:
+            // q|k|v at M = 1600 30.7 -> 24.6 us, FFN-in at M = 800 28.8 -> 22.2, FFN-out at M = 1600 split in 3 42.6 -> 35.0; below
+            // ~150 tiles the 64x64 kernel wins: projection at M = 1600 14.0 vs 19.0).  It has no second P8 copy of the result (c2).
+            if (S == 1 && g.force_cfg < 0 && !g.c2) {
+                const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+                if (t128 >= 150) cfg = 28;
+                else if (g.K >= 2048 && 3 * t128 >= 150 && (int64_t)3 * g.M * g.N <= cw.splitk_floats) { S = 3; cfg = 28; }
+                if (cfg == 28 && S == 1) g.force_cfg = 28;
+            }
             if (S > 1) { g.splitk = S; g.partial = cw.splitk; if (g.force_cfg < 0) g.force_cfg = cfg; }
         } else if (tiles < lim) {
             int S = std::min(std::min(g.K / 64, (tgt + tiles - 1) / tiles), 16);

@@ -987,6 +987,220 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Mid-grid kernel for the 50- / 100-token AR scale steps and the VAE stacks (M = 800 ... 3200 rows, K = 768 / 3072): 128x128 tiles,
+// ONE workgroup of 8 waves (2 x 4, wave tile 64 x 32) per CU and a ring of 4 stages of 32 KiB, three K tiles (96 KiB) in flight.
+// At these sizes a launch is one or two rounds and a round is bound by DMA latency per K step: the 64x64 small-grid kernel
+// (6 MFMAs per wave per step against a ~1.2 us fetch, three 16 KiB stages in flight per workgroup) takes 24 K steps x ~0.5 us per
+// round of 512 tiles, and 900 tiles (q|k|v at M = 1600) are two rounds; one 128x128 tile per CU has four times the matrix work per
+// fetched byte and the same bytes in flight.  Split-K capable (partial slabs as the small-grid kernel) for the N = 768 GEMMs.
+template <int STAGES, int TAG>
+__global__ __launch_bounds__(512, 1) void gemm_p8_mid_kernel(const GemmArgs g) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int WN_WAVES = (BM == 128) ? 4 : 2;          // waves along N
+    constexpr int TN = BN / WN_WAVES / 32;                 // n-tiles per wave (1 or 2); m-tiles per wave = 2
+    constexpr int APIECES = BM / 64, WPIECES = 2;          // 1-KiB DMA pieces per wave per stage
+    constexpr int NDMA = APIECES + WPIECES;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static_assert(STAGES * STAGE_BYTES <= 160 * 1024, "LDS");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    int tm, tn;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GM = (BM == 128) ? 4 : 2;
+        const int width = GM * tiles_n;
+        const int group = idx / width, first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        const int in_g = idx - group * width;
+        tn = in_g / gsz;
+        tm = first_m + (in_g - tn * gsz);
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk_all_ = g.K / BK, kt0 = (int)((long)nk_all_ * blockIdx.y / g.splitk);     // split-K: first K tile of this workgroup
+
+    // ---- DMA addressing: 1-KiB pieces (8 rows x 128 B); lane = (row in piece, physical chunk) ----
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const unsigned char* asrc[APIECES];
+    const unsigned char* wsrc[WPIECES];
+#pragma unroll
+    for (int q = 0; q < APIECES; ++q) {
+        const int ra = (wave * APIECES + q) * 8 + prow;                 // tile row 0..BM-1
+        const int gm = min(m0 + ra, g.M - 1);                           // clamp: rows >= M are never stored
+        asrc[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)gm * g.lda) * 4 + ((pchunk ^ ((ra >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int q = 0; q < WPIECES; ++q) {
+        const int rw = (wave * WPIECES + q) * 8 + prow;
+        const int gn = min(n0 + rw, g.N - 1);
+        wsrc[q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw) * 4 + ((pchunk ^ ((rw >> 1) & 7)) << 4);
+    }
+    // piece q of this wave for K tile kt into ring buffer buf: q < APIECES -> A rows, else W rows
+    auto issue_piece = [&](int q, int kt, int buf) {
+        unsigned char* base = smem_p8 + buf * STAGE_BYTES;
+        const long koff = (long)(kt0 + kt) * (BK * 4);
+        if (q < APIECES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[q] + koff),
+                                             (__attribute__((address_space(3))) void*)(base + (wave * APIECES + q) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q - APIECES] + koff),
+                                             (__attribute__((address_space(3))) void*)(base + BM * 128 + (wave * WPIECES + q - APIECES) * 1024), 16, 0, 0);
+    };
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int q = 0; q < NDMA; ++q) issue_piece(q, kt, buf);
+    };
+
+    const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
+    const int r = lane & 31, h = lane >> 5;
+    // LDS byte addresses of this lane's fragments inside a stage, [kb][hi/lo]; the second m tile (and n tile) is 32 rows = 4096 B
+    // further on with the same swizzle key, which goes into the instruction's immediate offset
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_p8;
+    unsigned a_off[2][2], w_off[2][2];
+    {
+        const int arow = wm * 64 + r, wrow = wn * (32 * TN) + r;
+        const int akey = (arow >> 1) & 7, wkey = (wrow >> 1) & 7;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int lo = 0; lo < 2; ++lo) {
+                const int c = (kb * 2 + h) * 2 + lo;     // logical 16-byte chunk: hi fragment, lo = the next one
+                a_off[kb][lo] = lds0 + arow * 128 + ((c ^ akey) << 4);
+                w_off[kb][lo] = lds0 + BM * 128 + wrow * 128 + ((c ^ wkey) << 4);
+            }
+    }
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (int)((long)nk_all_ * (blockIdx.y + 1) / g.splitk) - kt0;      // K tiles [kt0, kt0 + nk); split-K workgroups write raw partial slabs
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st < nk) issue(st, st);
+
+    // Fragment registers are one half-step ahead of the MFMAs, so LDS-read latency and the stage hand-over (vmcnt wait +
+    // barrier) sit under matrix work instead of in front of it.  Steady-state iteration kt (branch-free, so that hipcc counts
+    // its lgkmcnt waits exactly instead of draining at a join):
+    //   read kb=1 frags of stage kt | 6 MFMA kb=0 | vmcnt: stage kt+1 landed | barrier |
+    //   read kb=0 frags of stage kt+1 | 6 MFMA kb=1 with the DMA pieces of stage kt+S-1 issued one per MFMA gap
+    // The DMA reuses the buffer of stage kt-1, whose fragment reads were all consumed by MFMAs issued before this barrier, so no
+    // lgkmcnt drain is needed in front of the barrier and the kb=1 reads of stage kt stay in flight across it.
+    constexpr int NRD = 4 + 2 * TN;    // ds_read_b128 per half step
+    auto read_frags = [&](int buf, int kb, f16x8 (&ah)[2], f16x8 (&al)[2], f16x8 (&bh)[TN], f16x8 (&bl)[TN]) {
+        const unsigned sb = buf * STAGE_BYTES;
+        const unsigned ahp = a_off[kb][0] + sb, alp = a_off[kb][1] + sb, whp = w_off[kb][0] + sb, wlp = w_off[kb][1] + sb;
+        bh[0] = lds_read128<0>(whp);
+        ah[0] = lds_read128<0>(ahp);
+        bl[0] = lds_read128<0>(wlp);
+        al[0] = lds_read128<0>(alp);
+        ah[1] = lds_read128<4096>(ahp);
+        al[1] = lds_read128<4096>(alp);
+        if constexpr (TN == 2) {
+            bh[TN - 1] = lds_read128<4096>(whp);
+            bl[TN - 1] = lds_read128<4096>(wlp);
+        }
+    };
+    constexpr int NMF = 2 * TN * 3;    // MFMAs per half step
+    auto mfma_slot = [&](int sidx, const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
+        // term-major order: consecutive MFMAs go to different accumulators.  Weight fragment = A operand: C^T, see epilogue_tile32
+        const int t = sidx / (2 * TN), i = (sidx / TN) % 2, j = sidx % TN;
+        if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+    };
+    auto mfmas = [&](const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
+#pragma unroll
+        for (int sidx = 0; sidx < NMF; ++sidx) mfma_slot(sidx, ah, al, bh, bl);
+    };
+
+    f16x8 ah0[2], al0[2], bh0[TN], bl0[TN], ah1[2], al1[2], bh1[TN], bl1[TN];
+    wait_vmcnt_units<NDMA>(min(STAGES - 2, nk - 1));   // stage 0 landed (the prologue left up to STAGES-2 younger stages in flight)
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, ah0, al0, bh0, bl0);
+    int kt = 0, buf = 0;                               // buf = kt % STAGES
+    for (; kt + STAGES - 1 < nk; ++kt) {               // steady state: stage kt+S-1 still to be fetched
+        const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
+        const int fbuf = (buf == 0) ? STAGES - 1 : buf - 1;     // (kt + S - 1) % S
+        read_frags(buf, 1, ah1, al1, bh1, bl1);
+        wait_lgkmcnt<NRD>();                           // the kb=0 fragments (issued half a step ago) are in; the kb=1 reads fly on
+        mfmas(ah0, al0, bh0, bl0);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt<(STAGES - 3) * NDMA>();             // stage kt+1 landed for this wave (stages kt+2 .. kt+S-2 may still fly)
+        __builtin_amdgcn_s_barrier();                  // ... and for every wave; every wave is done with stage kt-1
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(nbuf, 0, ah0, al0, bh0, bl0);
+        wait_lgkmcnt<NRD>();                           // kb=1 fragments of stage kt
+#pragma unroll
+        for (int sidx = 0; sidx < NMF; ++sidx) {
+            mfma_slot(sidx, ah1, al1, bh1, bl1);
+            if (sidx < NDMA) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece(sidx, kt + STAGES - 1, fbuf);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nbuf;
+    }
+    for (; kt < nk; ++kt) {                            // drain: the last S-1 stages are in flight or landed
+        const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
+        read_frags(buf, 1, ah1, al1, bh1, bl1);
+        wait_lgkmcnt<NRD>();
+        mfmas(ah0, al0, bh0, bl0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            wait_vmcnt_units<NDMA>(min(STAGES - 3, nk - 2 - kt));
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(nbuf, 0, ah0, al0, bh0, bl0);
+            wait_lgkmcnt<NRD>();
+        } else {
+            wait_lgkmcnt<0>();
+        }
+        mfmas(ah1, al1, bh1, bl1);
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nbuf;
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
+    if (g.splitk > 1) {      // raw sums; splitk_reduce[_ln768]_kernel finishes them
+        float* __restrict__ P = g.partial + (long)blockIdx.y * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) partial_tile32(g, P, m0 + wm * 64 + i * 32 + r, n0 + wn * (32 * TN) + j * 32, h, acc[i][j]);
+        return;
+    }
+    const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+    if (epi.vec) {      // coalesced: transpose through this wave's slice of the (now idle) stage ring
+        __builtin_amdgcn_s_barrier();      // every wave has consumed its last fragments
+        constexpr int SLICE = 64 * (32 * TN + 4);
+        static_assert(8 * SLICE * 4 <= STAGES * STAGE_BYTES, "epilogue LDS");
+        epilogue_wave_lds<2, TN, true>(g, epi, reinterpret_cast<float*>(smem_p8) + wave * SLICE, m0 + wm * 64, n0 + wn * (32 * TN), lane, acc);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) epilogue_tile32<true, true>(g, epi, m0 + wm * 64 + i * 32 + r, n0 + wn * (32 * TN) + j * 32, h, acc[i][j]);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
 // Small-grid variant for the AR/VAE scale steps (M = clips x 1..100 tokens): these launches are bound by the latency of ONE
 // tile, and the register-staged kernel's single K tile of prefetch costs ~1 us per K step (a 64x64 tile over K = 768 took
 // 23-28 us whatever M was).  Here a 64x64 (or 128x64) tile is fed by the same LDS-DMA ring as the big kernels, STAGES-1 K
@@ -1377,9 +1591,17 @@ bool gemm_p8_sm_eligible(const GemmArgs& g) {
 // slice should be in flight at once (the launch then costs one memory latency instead of one per K step): 23: 64x64 x 8 stages
 // (128 KiB, one workgroup per CU), 24: 64x64 x 5 stages (80 KiB, two per CU).  (128x64, 64x128 and 128x128 tiles and a 3-stage ring
 // were measured on the unsplit grids of the 50- / 100-token steps and never won: DESIGN.md section 6.)
+void gemm_p8_prepare();
+static void launch_p8_mid(const GemmArgs& g, hipStream_t s) {
+    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    gemm_p8_prepare();
+    if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_mid_kernel<4, 1>), dim3(tiles, g.splitk), dim3(512), 4 * 256 * 128, s, g);
+    else hipLaunchKernelGGL((gemm_p8_mid_kernel<4, 0>), dim3(tiles, g.splitk), dim3(512), 4 * 256 * 128, s, g);
+}
 void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return;
     switch (g.force_cfg) {
+        case 28: launch_p8_mid(g, s); break;
         case 23: launch_p8_sm_cfg<64, 64, 8>(g, s); break;
         case 24: launch_p8_sm_cfg<64, 64, 5>(g, s); break;
         default: launch_p8_sm_cfg<64, 64, 4>(g, s); break;
@@ -1408,6 +1630,8 @@ void gemm_p8_prepare() {      // more than the default 64 KB of dynamic LDS (out
                           reinterpret_cast<const void*>(&gemm_p8_big_kernel<5, true, 0>), reinterpret_cast<const void*>(&gemm_p8_big_kernel<5, true, 1>)};
     for (const void* f : big4) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096);
     for (const void* f : big5) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 576 * 128 + 4096);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_mid_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_mid_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128);
     done[dev] = true;
 }
 // Production kernels: force_cfg 7 / 12 = gemm_p8_big_kernel with 256 x 256 / 320 x 256 tiles (persistent, one workgroup per CU),
