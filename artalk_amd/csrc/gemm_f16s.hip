@@ -563,10 +563,10 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
         bh[kb][1] = lds_read128<4096>(hp);
         bl[kb][1] = lds_read128<4096>(lp);
     };
-    // One K step out of ring buffer `buf`.  ISSUE (wave-uniform, a scalar branch per piece: ONE copy of the step's code serves every
-    // step of the kernel): the pieces of K tile kt_issue of the tile `src` points at go into the other buffer meanwhile, one per two MFMAs.  pre: vector-memory instructions that may stay in flight at the top (everything OLDER than them
-    // - in particular this step's stage - has landed).
-    auto kstep = [&](int buf, bool ISSUE, int kt_issue, int pre) __attribute__((always_inline)) {
+    // Top of a K step that reads ring buffer `buf`: its stage has landed for this wave (pre: vector-memory instructions that may stay in
+    // flight - everything OLDER than them has landed), then for every wave, and every wave is done reading the other buffer (barrier);
+    // then the fragments of the step's first sub-step are requested.
+    auto top = [&](int buf, int pre) __attribute__((always_inline)) {
         const unsigned sb = buf * STAGE_BYTES;
         if (pre == 16) wait_vmcnt<16>();                                  // later tiles with a residual: the last few sub-tiles' stores
         else if (pre == 1 + NDMA) wait_vmcnt<1 + NDMA>();                 // first tile, step 0: bias piece + stage 1
@@ -578,6 +578,15 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
         read_b(sb, 0);
         ah[0] = lds_read128<0>(a_off[0] + sb);
         al[0] = lds_read128<0>(a_off[1] + sb);
+    };
+    // One K step out of ring buffer `buf`; its top() has run.  ISSUE (wave-uniform, a scalar branch per piece: ONE copy of the step's
+    // code serves every step of the kernel): the pieces of K tile kt_issue of the tile `src` points at go into the other buffer
+    // meanwhile, one per two MFMAs.  next_top: the NEXT step's top() runs in front of this step's last sub-step - by then every
+    // fragment of this stage is in registers, the next stage (fetched during the first third of this step) has had 40+ MFMAs to land,
+    // and the next step's first fragments ride under the last six MFMAs instead of stalling both waves of a SIMD at the step boundary
+    // (same-process A/B, interleaved rounds, profiles/r03_gemm_early_top_ab.log: 1.4 - 3.4 % of the whole launch).
+    auto kstep = [&](int buf, bool ISSUE, int kt_issue, bool next_top, int next_pre) __attribute__((always_inline)) {
+        const unsigned sb = buf * STAGE_BYTES;
         static_for<0, NSUB>([&](auto u_tag) __attribute__((always_inline)) {
             constexpr int u = decltype(u_tag)::value, kb = u / TM, i = u % TM, sl = u & 1;
             if constexpr (u + 1 < NSUB) {       // prefetch the next sub-step's fragments, then wait for everything older than them
@@ -588,6 +597,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
                 if constexpr (ni == 0) wait_lgkmcnt<6>(); else wait_lgkmcnt<2>();
             } else {
                 wait_lgkmcnt<0>();
+                if (next_top) top(buf ^ 1, next_pre);      // (slot 0 and the k-block-0 weight fragments are free: this sub-step uses slot 1 / k block 1)
             }
 #pragma unroll
             for (int t = 0; t < 3; ++t)
@@ -641,12 +651,12 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
         // Stages 0 and 1 of a tile are in the ring when it starts.  Step kt reads buffer gs & 1 and fetches K tile kt + 1 into the
         // other one - except step 0, whose K tile 1 is there already (K tile 2 would need the buffer step 0 itself reads).  The last
         // step runs the ring on into the next tile: its stage 0 goes into the buffer of the step before.
+        top(gs & 1, nk > 1 ? pre0 : 0);      // (nk == 1: stage 0 only, waited for in full)
 #pragma nounroll
         for (int kt = 0; kt < nk; ++kt) {
             const bool last = kt + 1 == nk;
             if (last && has_next) set_src(nm0, nn0);
-            const int pre = kt == 0 ? (nk > 1 ? pre0 : 0) : (kt == 1 ? pre1 : 0);      // (nk == 1: stage 0 only, waited for in full)
-            kstep(gs & 1, last ? has_next : kt >= 1, last ? 0 : kt + 1, pre);
+            kstep(gs & 1, last ? has_next : kt >= 1, last ? 0 : kt + 1, !last, kt == 0 ? pre1 : 0);
             ++gs;
         }
         if (has_next) issue_bias((tile_no + 1) & 1);

@@ -46,12 +46,15 @@ for name, M, N, K in SHAPES:
     Cc = torch.empty(M, N, device="cuda")
     ref = A[:256].double() @ W.double().t() + b.double()
     line = f"{name:12s} M={M:6d} N={N:5d} K={K:4d} "
+    # variants are timed in INTERLEAVED rounds (A B C A B C ...) and reported by their median: box temperature and clock state drift by
+    # several per cent over a process, which a variant-after-variant order turns into a bias
+    runs = []
     for cfg, apk in variants:
-        best = 1e9
         n = 3 if M * N * K > 1e11 else (10 if ROT == 1 else ROT)
         a = Ap if apk else A
         L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wp), p(b), p(Cc), M, N, K, ACT, cfg, s)      # warm-up (allocates the split-K scratch)
         torch.cuda.synchronize()
+        err = float((Cc[:256].double() - ref).abs().max() / ref.abs().max())
         graph = None
         if os.environ.get("GEMM_GRAPH", "1") == "1" and M * N * K < 1e11:
             # the launches replayed from a hipGraph, as the model runs them: eager launches are host-bound below ~3.5 us per kernel
@@ -60,16 +63,20 @@ for name, M, N, K in SHAPES:
                 gs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
                 for it in range(n):
                     L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wps[it % ROT]), p(b), p(Cc), M, N, K, ACT, cfg, gs)
-        for rnd in range(3):
+        runs.append(dict(cfg=cfg, apk=apk, a=a, n=n, graph=graph, err=err, ts=[]))
+    for rnd in range(int(os.environ.get("GEMM_ROUNDS", "5"))):
+        for v in runs:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            if graph is not None:
-                graph.replay()
+            if v["graph"] is not None:
+                v["graph"].replay()
             else:
-                for it in range(n):
-                    L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wps[it % ROT]), p(b), p(Cc), M, N, K, ACT, cfg, s)
+                for it in range(v["n"]):
+                    L.artalk_op_gemm_f16s_packed(p(v["a"]), v["apk"], K, p(Wps[it % ROT]), p(b), p(Cc), M, N, K, ACT, v["cfg"], s)
             e1.record(); torch.cuda.synchronize()
-            best = min(best, e0.elapsed_time(e1) / n)
-        err = float((Cc[:256].double() - ref).abs().max() / ref.abs().max())
-        line += f"| cfg{cfg & 0xff}{'/%d' % (cfg >> 8) if cfg >> 8 else ''}{'P' if apk else ' '}: {best*1e3:8.1f} us {2*M*N*K/best/1e9:6.1f} TF e={err:.0e} "
+            v["ts"].append(e0.elapsed_time(e1) / v["n"])
+    for v in runs:
+        best = sorted(v["ts"])[len(v["ts"]) // 2]
+        cfg = v["cfg"]
+        line += f"| cfg{cfg & 0xff}{'/%d' % (cfg >> 8) if cfg >> 8 else ''}{'P' if v['apk'] else ' '}: {best*1e3:8.1f} us {2*M*N*K/best/1e9:6.1f} TF e={v['err']:.0e} "
     print(line, flush=True)
