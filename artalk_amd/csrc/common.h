@@ -34,6 +34,30 @@ __device__ __forceinline__ float gelu_erf(float x) {
     const float h = 0.5f * __builtin_amdgcn_exp2f(p * t);
     return x * (z < 0.f ? h : 1.0f - h);
 }
+// The same on two values at once: the polynomial and the scalings run on the packed-fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: two
+// lanes' worth of fp32 per instruction on gfx950), bit-identical to gelu_erf per element.  For kernels that are VALU-bound on it (conv0).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 z = x * 0.70710678118654752440f;
+    f32x2 t;
+    t.x = fminf(fabsf(z.x), 4.0f); t.y = fminf(fabsf(z.y), 4.0f);
+    f32x2 p = {0x1.8564d6p-17f, 0x1.8564d6p-17f};
+    p = __builtin_elementwise_fma(p, t, (f32x2)(-0x1.40ca46p-13f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(0x1.bcb83cp-11f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(-0x1.2a2936p-9f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(0x1.63b57cp-14f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(0x1.c63cep-6f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(-0x1.2fbc0ep-3f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(-0x1.d63e26p-1f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(-0x1.a0be88p+0f));
+    p = p * t;
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(p.x); e.y = __builtin_amdgcn_exp2f(p.y);
+    const f32x2 hpos = __builtin_elementwise_fma(e, (f32x2)(-0.5f), (f32x2)(1.0f)), hneg = e * 0.5f;      // 1 - h, h
+    f32x2 phi;
+    phi.x = z.x < 0.f ? hneg.x : hpos.x; phi.y = z.y < 0.f ? hneg.y : hpos.y;
+    return x * phi;
+}
 // gelu(approximate='tanh'): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3), through the identity 0.5 (1 + tanh u) = 1 / (1 + e^(-2u)):
 // one v_exp_f32 and one v_rcp_f32 (8 instructions; libm's tanhf about 35), no cancellation.  2.3 ulp against float64 for x > 0
 // (the libm formula in fp32: 1.7 ulp).  The constants are -2 sqrt(2/pi) log2(e) and that times 0.044715.

@@ -503,11 +503,14 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
     derive();
 
     // tile index -> origin: XCD-contiguous (workgroups b and b + 8 share an XCD and gridDim.x % 8 == 0, so tile t runs on XCD t & 7),
-    // grouped column-major inside groups of 8 row tiles (8 x 4 tiles per XCD at a time)
+    // grouped column-major inside groups of GM row tiles
     auto tile_origin = [&](int t, int& m0, int& n0) __attribute__((always_inline)) {
         const int xcd = t & 7, q = ntiles >> 3, rr = ntiles & 7;
         const int idx = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
-        constexpr int GM = 8;
+        // row tiles per group: 8 (an XCD then works on ~8 x 4 tiles at a time) - or ALL of them when there are few (the AdaLN table:
+        // 23 row tiles x 222 column tiles; with groups of 8 every XCD walked all 222 column tiles and pulled the whole 233 MB weight
+        // matrix, 2.0 GB read per launch; column-major over all rows an XCD reads an eighth of it)
+        const int GM = tiles_m <= 32 ? tiles_m : 8;
         const int width = GM * tiles_n;
         const int group = idx / width, first_m = group * GM;
         const int gsz = min(tiles_m - first_m, GM);
@@ -518,33 +521,35 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
     };
 
     // DMA source addressing: piece q of a wave covers tile rows (wave * TM + q) * 8 + prow (A) / (wave * 4 + q) * 8 + prow (W); lane =
-    // (row in piece, physical 16-byte chunk).  Only the offset of the lane's row in piece 0 and its swizzle term are kept in registers
-    // (32-bit byte offsets from the operand bases: the launcher takes this kernel only for operands below 4 GiB); a piece's offset is
-    // min(row0 + q * 8 rows, last row) + swizzle, three VALU instructions at issue time - nine stored offsets were what pushed the
-    // 320-row tile into spilling.  Swizzle: chunk ^ ((row >> 1) & 7) with row = 8 * piece + prow, i.e. (piece & 1) * 4 + (prow >> 1).
+    // (row in piece, physical 16-byte chunk).  The pieces are BUFFER loads to LDS (buffer_load_dwordx4 ... offen lds): the operand is
+    // described once by a resource descriptor in scalar registers, the lane's byte offset is 32 bits (the launcher takes this kernel
+    // only for operands below 4 GiB), the K offset rides in the instruction's scalar offset, and rows beyond the operand's last row
+    // (edge tiles) are dropped by the hardware's range check and land as zeros - no clamp.  A piece costs two VALU instructions
+    // (row offset of piece q, swizzle), one scalar add for M0 and the load; the flat form (64-bit address per lane, min(), carry
+    // chain) took eleven instructions per piece, and this kernel is bound by what its two waves per SIMD issue BETWEEN their MFMAs
+    // (hardware counters: the matrix pipe busy 75 % of the cycles with every wait and barrier removed).
+    // Only the offset of the lane's row in piece 0 and its swizzle term live in registers - nine stored offsets were what pushed
+    // the 320-row tile into spilling.  Swizzle: chunk ^ ((row >> 1) & 7) with row = 8 * piece + prow, i.e. (piece & 1) * 4 + (prow >> 1).
     unsigned a_row0 = 0, w_row0 = 0, swz = 0;        // byte offsets of the lane's row of piece 0; (pchunk ^ (prow >> 1)) << 4
-    unsigned a_last = 0, w_last = 0;                 // (wave-uniform) offsets of the operands' last rows: the clamp of edge tiles
     const unsigned a_step = (unsigned)(8 * g.lda * 4), w_step = (unsigned)(8 * g.ldw * 4);
-    const unsigned char* const Abase = reinterpret_cast<const unsigned char*>(g.A);
-    const unsigned char* const Wbase = reinterpret_cast<const unsigned char*>(g.Wp);
+    // descriptors: base, stride 0 (raw), bytes up to the end of the last row's K run, 32-bit data format
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0,
+                                                                            (int)(((unsigned)(g.M - 1) * (unsigned)g.lda + (unsigned)g.K) * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(g.Wp), 0,
+                                                                            (int)(((unsigned)(g.N - 1) * (unsigned)g.ldw + (unsigned)g.K) * 4u), 0x00020000);
     const unsigned char* const Bbase = g.bias ? reinterpret_cast<const unsigned char*>(g.bias) : reinterpret_cast<const unsigned char*>(g.Wp);
     int bias_col0 = 0;                               // (wave-uniform) first bias column of this wave for the tile `src` points at
     auto set_src = [&](int m0, int n0) __attribute__((always_inline)) {
         a_row0 = (unsigned)(m0 + wave * TM * 8 + prow) * (unsigned)(g.lda * 4);
         w_row0 = (unsigned)(n0 + wave * 32 + prow) * (unsigned)(g.ldw * 4);
-        a_last = (unsigned)(g.M - 1) * (unsigned)(g.lda * 4);
-        w_last = (unsigned)(g.N - 1) * (unsigned)(g.ldw * 4);
         swz = (unsigned)((pchunk ^ (prow >> 1)) << 4);
         bias_col0 = n0 + wn * 64;
     };
     auto issue_piece = [&](int q, int kt, int buf) __attribute__((always_inline)) {
         unsigned char* dst = smem_p8 + buf * STAGE_BYTES + (q < TM ? (wave * TM + q) * 1024 : BM * 128 + (wave * 4 + q - TM) * 1024);
         const int p = q < TM ? wave * TM + q : wave * 4 + q - TM;             // piece index inside the operand's tile (wave-uniform)
-        const unsigned off = (q < TM ? min(a_row0 + (unsigned)q * a_step, a_last) : min(w_row0 + (unsigned)(q - TM) * w_step, w_last)) +
-                             (swz ^ (unsigned)((p & 1) << 6));
-        const unsigned char* base = (q < TM ? Abase : Wbase) + (long)kt * (BK * 4);      // wave-uniform
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        const unsigned off = (q < TM ? a_row0 + (unsigned)q * a_step : w_row0 + (unsigned)(q - TM) * w_step) + (swz ^ (unsigned)((p & 1) << 6));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(q < TM ? a_rsrc : w_rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)off, kt * (BK * 4), 0, 0);
     };
     auto issue_bias = [&](int slot) __attribute__((always_inline)) {
         // this wave's 64 bias values, one float per lane (without a bias: any valid address, the slot is then unused)
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
 
     f32x16 acc[TM][2];
     f16x8 bh[2][2], bl[2][2];      // [k block][n tile]
-    f16x8 ah[2], al[2];            // two slots, sub-step u lives in slot u & 1
+    f16x8 ah[2], al[2];            // two slots, sub-step u lives in slot u & 1 (requesting fragments two sub-steps ahead measured no gain)
     auto read_b = [&](unsigned sb, int kb) __attribute__((always_inline)) {
         const unsigned hp = (w_off[0] + sb) ^ (kb << 6), lp = (w_off[1] + sb) ^ (kb << 6);
         bh[kb][0] = lds_read128<0>(hp);
@@ -568,10 +573,13 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
     // then the fragments of the step's first sub-step are requested.
     auto top = [&](int buf, int pre) __attribute__((always_inline)) {
         const unsigned sb = buf * STAGE_BYTES;
-        if (pre == 16) wait_vmcnt<16>();                                  // later tiles with a residual: the last few sub-tiles' stores
-        else if (pre == 1 + NDMA) wait_vmcnt<1 + NDMA>();                 // first tile, step 0: bias piece + stage 1
-        else if (pre == 8 * TM) wait_vmcnt<8 * TM>();                     // later tiles, step 1: the previous tile's stores
-        else if (pre == 8 * TM + 1 + NDMA) wait_vmcnt<8 * TM + 1 + NDMA>();   // later tiles, step 0: bias piece + stage 1 + stores
+        // the largest count of the ladder that does not exceed `pre` (waiting for more than asked is always safe)
+        if (pre >= 8 * TM + 1 + NDMA) wait_vmcnt<8 * TM + 1 + NDMA>();    // later tiles, step 0: bias piece + stage 1 + the previous tile's stores
+        else if (pre >= 8 * TM + NDMA) wait_vmcnt<8 * TM + NDMA>();       // later tiles, step 1: those stores + step 0's re-fetched pieces
+        else if (pre >= 16 + NDMA) wait_vmcnt<16 + NDMA>();               // the same with a residual (the last few sub-tiles' stores)
+        else if (pre >= 16) wait_vmcnt<16>();
+        else if (pre >= 1 + NDMA) wait_vmcnt<1 + NDMA>();                 // first tile, step 0: bias piece + stage 1
+        else if (pre >= NDMA) wait_vmcnt<NDMA>();                         // first tile, step 1: step 0's re-fetched pieces
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -579,13 +587,14 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
         ah[0] = lds_read128<0>(a_off[0] + sb);
         al[0] = lds_read128<0>(a_off[1] + sb);
     };
-    // One K step out of ring buffer `buf`; its top() has run.  ISSUE (wave-uniform, a scalar branch per piece: ONE copy of the step's
-    // code serves every step of the kernel): the pieces of K tile kt_issue of the tile `src` points at go into the other buffer
-    // meanwhile, one per two MFMAs.  next_top: the NEXT step's top() runs in front of this step's last sub-step - by then every
+    // One K step out of ring buffer `buf`; its top() has run.  The pieces of K tile kt_issue of the tile `src` points at go into the
+    // other buffer meanwhile, one per two MFMAs - in EVERY step, so that the step is straight-line code (ONE copy serves the whole
+    // kernel, no branch per piece): the two steps that have nothing new to fetch re-fetch what the other buffer holds or will not
+    // need (the callers' comments).  next_top: the NEXT step's top() runs in front of this step's last sub-step - by then every
     // fragment of this stage is in registers, the next stage (fetched during the first third of this step) has had 40+ MFMAs to land,
     // and the next step's first fragments ride under the last six MFMAs instead of stalling both waves of a SIMD at the step boundary
     // (same-process A/B, interleaved rounds, profiles/r03_gemm_early_top_ab.log: 1.4 - 3.4 % of the whole launch).
-    auto kstep = [&](int buf, bool ISSUE, int kt_issue, bool next_top, int next_pre) __attribute__((always_inline)) {
+    auto kstep = [&](int buf, int kt_issue, bool next_top, int next_pre) __attribute__((always_inline)) {
         const unsigned sb = buf * STAGE_BYTES;
         static_for<0, NSUB>([&](auto u_tag) __attribute__((always_inline)) {
             constexpr int u = decltype(u_tag)::value, kb = u / TM, i = u % TM, sl = u & 1;
@@ -607,7 +616,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
                     else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kb][j], ah[sl], acc[i][j], 0, 0, 0);
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], al[sl], acc[i][j], 0, 0, 0);
                     const int piece = u * 3 + t;     // one DMA piece per two MFMAs from the start of the step
-                    if (ISSUE && j == 1 && piece < NDMA) {
+                    if (j == 1 && piece < NDMA) {
                         __builtin_amdgcn_sched_barrier(0);
                         issue_piece(piece, kt_issue, buf ^ 1);
                         __builtin_amdgcn_sched_barrier(0);
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
         for (int q = 0; q < NDMA; ++q) issue_piece(q, 1, 1);
     }
     // vector-memory instructions issued after the stage that K step 0 / K step 1 of the current tile reads (see kstep's `pre`)
-    int pre0 = 1 + (nk > 1 ? NDMA : 0), pre1 = 0;
+    int pre0 = 1 + (nk > 1 ? NDMA : 0), pre1 = 0;       // (+ NDMA for step 1: the pieces step 0 re-fetches)
     int gs = 0, tile_no = 0;        // ring parity (K steps run so far), bias slot parity
     while (true) {
         if (tile_no > 0) { derive(); set_src(m0, n0); }      // (see derive(): the epilogue's registers end here)
@@ -649,14 +658,16 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
         int nm0 = 0, nn0 = 0;
         if (has_next) tile_origin(t_next, nm0, nn0);
         // Stages 0 and 1 of a tile are in the ring when it starts.  Step kt reads buffer gs & 1 and fetches K tile kt + 1 into the
-        // other one - except step 0, whose K tile 1 is there already (K tile 2 would need the buffer step 0 itself reads).  The last
-        // step runs the ring on into the next tile: its stage 0 goes into the buffer of the step before.
+        // other one; for step 0 that is the K tile the other buffer already holds (K tile 2 would need the buffer step 0 itself reads):
+        // the same bytes land on themselves, which is harmless under the reads of the next step's first fragments, and 1 / nk more
+        // traffic buys a branch-free step.  The last step runs the ring on into the next tile: its stage 0 goes into the buffer of the
+        // step before; the very last step of the workgroup re-fetches K tile 0 of its own tile into that (free) buffer.
         top(gs & 1, nk > 1 ? pre0 : 0);      // (nk == 1: stage 0 only, waited for in full)
 #pragma nounroll
         for (int kt = 0; kt < nk; ++kt) {
             const bool last = kt + 1 == nk;
             if (last && has_next) set_src(nm0, nn0);
-            kstep(gs & 1, last ? has_next : kt >= 1, last ? 0 : kt + 1, !last, kt == 0 ? pre1 : 0);
+            kstep(gs & 1, last ? 0 : kt + 1, !last, kt == 0 ? pre1 + NDMA : 0);
             ++gs;
         }
         if (has_next) issue_bias((tile_no + 1) & 1);
@@ -724,11 +735,12 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
         // and bias piece included; what is left are the stores behind the last load (at most three sub-tiles'), which 16 covers.
         const int stores = has_res ? 16 : 4 * NSUB;
         if (has_res) behind = 0;
-        if (!has_next) break;
+        if (!has_next) break;      // (the re-fetched pieces of the last step are still in flight: waited for below)
         // the next tile's K step 0 needs its stage 0: everything issued behind it may stay in flight if it can be counted
         pre0 = behind + stores; pre1 = stores;
         t = t_next; m0 = nm0; n0 = nn0; ++tile_no;
     }
+    wait_vmcnt<0>();      // no LDS-DMA of this workgroup may outlive it (the LDS goes to the CU's next workgroup)
 }
 
 // ------------------------------------------------------------------------------------------------------------------

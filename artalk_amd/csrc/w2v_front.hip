@@ -58,15 +58,17 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
                                                     const float* __restrict__ lnb, float* __restrict__ Y, int T, int row_stride, int* __restrict__ status, int out_p8) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.y;
-    int ch[8];
+    // channel pairs (2 jj, 2 jj + 1) of this lane in packed-fp32 registers: the 80 taps, the LayerNorm and the GELU polynomial run on
+    // v_pk_fma_f32 (two channels per instruction).  The kernel was bound by this arithmetic, not by its 2.5 GB of stores.
+    f32x2 wt[4][10], bs[4], gw[4], gb[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ch[j] = (j >> 2) * 256 + lane * 4 + (j & 3);
-    float wt[8][10], bs[8], gw[8], gb[8];
+    for (int jj = 0; jj < 4; ++jj) {
+        const int c0 = (jj >> 1) * 256 + lane * 4 + (jj & 1) * 2;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int k = 0; k < 10; ++k) wt[j][k] = w[ch[j] * 10 + k];
-        bs[j] = bias[ch[j]]; gw[j] = lnw[ch[j]]; gb[j] = lnb[ch[j]];
+        for (int k = 0; k < 10; ++k) { wt[jj][k].x = w[c0 * 10 + k]; wt[jj][k].y = w[(c0 + 1) * 10 + k]; }
+        bs[jj].x = bias[c0]; bs[jj].y = bias[c0 + 1];
+        gw[jj].x = lnw[c0]; gw[jj].y = lnw[c0 + 1];
+        gb[jj].x = lnb[c0]; gb[jj].y = lnb[c0 + 1];
     }
     const float* x = xn + (long)c * n;
     for (int t = blockIdx.x * 4 + wv; t < T; t += gridDim.x * 4) {
@@ -75,29 +77,35 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
         float xs[10];
 #pragma unroll
         for (int k = 0; k < 10; ++k) xs[k] = __shfl(xv, k, 64);
-        float v[8];
+        f32x2 v[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            f32x2 acc = bs[jj];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) acc = __builtin_elementwise_fma(wt[jj][k], (f32x2)(xs[k]), acc);      // same order per channel as the scalar form
+            v[jj] = acc;
+        }
+        // (the sums keep the scalar kernel's order: channels 0..7 of the lane one after the other, then the wave butterfly)
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float acc = bs[j];
-#pragma unroll
-            for (int k = 0; k < 10; ++k) acc = fmaf(wt[j][k], xs[k], acc);
-            v[j] = acc; s += acc;
-        }
+        for (int jj = 0; jj < 4; ++jj) { s += v[jj].x; s += v[jj].y; }
         const float mean = wave_sum(s) * (1.0f / 512.0f);
         float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; q += d * d; }
+        for (int jj = 0; jj < 4; ++jj) {
+            const f32x2 d = v[jj] - mean;
+            q = fmaf(d.x, d.x, q); q = fmaf(d.y, d.y, q);
+        }
         const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 512.0f) + 1e-5f);
-        float o[8];
+        f32x2 o[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = gelu_erf((v[j] - mean) * rstd * gw[j] + gb[j]);
+        for (int jj = 0; jj < 4; ++jj) o[jj] = gelu_erf2(__builtin_elementwise_fma((v[jj] - mean) * rstd, gw[jj], gb[jj]));
         float* y = Y + ((long)c * row_stride + t) * 512;
         if (out_p8) {
-            store_p8x4(y, lane * 4, o[0], o[1], o[2], o[3], status);
-            store_p8x4(y, 256 + lane * 4, o[4], o[5], o[6], o[7], status);
+            store_p8x4(y, lane * 4, o[0].x, o[0].y, o[1].x, o[1].y, status);
+            store_p8x4(y, 256 + lane * 4, o[2].x, o[2].y, o[3].x, o[3].y, status);
         } else {
-            f32x4 lo = {o[0], o[1], o[2], o[3]}, hi = {o[4], o[5], o[6], o[7]};
+            f32x4 lo = {o[0].x, o[0].y, o[1].x, o[1].y}, hi = {o[2].x, o[2].y, o[3].x, o[3].y};
             *reinterpret_cast<f32x4*>(y + lane * 4) = lo;
             *reinterpret_cast<f32x4*>(y + 256 + lane * 4) = hi;
         }

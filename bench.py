@@ -33,14 +33,16 @@ GFLOP_PER_FRAME = 2.159          # algorithmic work with KV cache, BASELINE.md s
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
 SUSTAINED_F16_MFMA_TFLOPS = 1780.0   # measured: register-only v_mfma_f32_32x32x16_f16 loop on non-trivial data holds a 1.75 GHz clock (profiles/r02_mfma_f16_peak.log)
-PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"      # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
+PMC_TRAFFIC_FILE = "profiles/r03_pmc_traffic.json"      # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
 MODES = {
     # precision -> (dtype string, dominant kernel symbol prefix in the PMC file, description, peak TF/s of ALGORITHMIC flops, note)
     "f32": ("f32", "gemm_f32_kernel<128, 128, 2, 2, 16, 0, 0>",
             "gemm_f32_kernel<128,128,2,2,16,0,0> (v_mfma_f32_32x32x2_f32): every launch of it (wav2vec2 conv/encoder GEMMs, AdaLN table)",
             PEAK_F32_MFMA_TFLOPS, "fp32 MFMA peak"),
-    "f16x3": ("f32 (operands split into 2 fp16, 3 fp16 MFMA products per fp32 product, fp32 accumulate)", "gemm_p8_256_kernel<0>",
-              "gemm_p8_256_kernel<0> (256x256 tiles, 8 waves of 128x64, LDS-DMA staged, v_mfma_f32_32x32x16_f16 x3 per k-block, coalesced epilogue through wave-private LDS): every launch of it (wav2vec2 q|k|v and FFN-in GEMMs, conv1-3 as GEMMs, AdaLN table); the out-projection / FFN-out GEMMs run on gemm_p8_2wgp_kernel (profiles/)",
+    "f16x3": ("f32 (operands split into 2 fp16, 3 fp16 MFMA products per fp32 product, fp32 accumulate)", "gemm_p8_big_kernel",
+              "gemm_p8_big_kernel<TM, RES> (persistent, one 8-wave workgroup per CU, 320x256 or 256x256 tiles, LDS-DMA ring running across tile "
+              "boundaries, v_mfma_f32_32x32x16_f16 x3 per k-block, stores straight from the accumulators behind counted vmcnt waits): every "
+              "launch of it = every large GEMM of the step (wav2vec2 q|k|v, out-projection, FFN-in, FFN-out, feature projection, conv1-6 as GEMMs, AdaLN table)",
               PEAK_F16_MFMA_TFLOPS / 3.0, "dense fp16 MFMA peak 2500 TF/s / 3 MFMA products per algorithmic product"),
 }
 GOLDEN_SET = os.path.join(REPO, "tests", "golden", "full_cfg2_synth8.npz")    # reference outputs for seeds 0..7 (even seeds unstyled)
@@ -330,9 +332,13 @@ def main():
         traffic, traffic_src = None, None
         tpath = os.path.join(REPO, PMC_TRAFFIC_FILE)
         if os.path.exists(tpath):
-            for k, v in json.load(open(tpath)).items():
+            tb, tn = 0.0, 0
+            for k, v in json.load(open(tpath)).items():      # every instantiation of the dominant kernel, weighted by its launches
                 if isinstance(v, dict) and k.startswith(MODES[args.precision][1]):
-                    traffic, traffic_src = round(v["hbm_bytes_per_launch"]), PMC_TRAFFIC_FILE
+                    tb += v["hbm_bytes_per_launch"] * v["launches_FETCH_SIZE"]
+                    tn += v["launches_FETCH_SIZE"]
+            if tn:
+                traffic, traffic_src = round(tb / tn), PMC_TRAFFIC_FILE
         dtype, _, kdesc, peak, peak_note = MODES[args.precision]
         roofline = {
             "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
