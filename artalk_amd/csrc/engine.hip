@@ -13,6 +13,7 @@
 #include "kernels.h"
 #include "../../include/artalk_hip.h"
 
+#include <hip/hip_ext.h>
 #include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <algorithm>
@@ -79,7 +80,6 @@ struct Workspace {
     float *fhat = nullptr, *nextfeat = nullptr;
     float* splitk = nullptr; int64_t splitk_floats = 0;   // partial sums of split-K GEMMs
     float* splitk_b[4] = {nullptr, nullptr, nullptr, nullptr};   // one scratch per concurrent branch of the AR body (splitk_b[0] == splitk)
-    float* splitk_w2v = nullptr;                                 // scratch of the wav2vec2 stream in the overlapped schedule
     uint8_t *bits = nullptr, *hist_bits = nullptr, *has_style = nullptr;
     int* status = nullptr;           // device word: bit 0 non-finite logit, bit 1 non-finite re-encoder output (see artalk_get_status)
     // VAE
@@ -110,6 +110,8 @@ struct artalk_model {
     unsigned int* audit_vals = nullptr;            // device, kAuditSlots floats (as bits)
     std::vector<std::string> audit_names;
     std::map<std::string, int> audit_index;
+    std::vector<uint32_t> cu_mask;    // artalk_set_cu_mask: the library's own streams are restricted to these compute units
+    int n_cus = 0;                    // their number (0 = the whole device): grid of the persistent one-workgroup-per-CU kernels
     int stream_B = 0;                 // streams opened by artalk_stream_begin (history lives in the workspace)
     Workspace* view = nullptr;        // workspace view (clip sub-range) the body launchers currently work on; null = m->ws
     bool sticky_error = false;        // set by internal consistency checks inside the launch sequence; reported by artalk_infer
@@ -141,13 +143,7 @@ struct artalk_model {
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     std::vector<std::pair<size_t, double>> dom_events;   // (event index of start, flops)
     std::vector<std::pair<int, size_t>> marks;          // (bucket of the interval ending here, event index), caller's stream
-    std::vector<std::pair<int, size_t>> marks_w2v;      // same for the wav2vec2 stream of the overlapped schedule
     hipStream_t prof_stream = nullptr;
-    // overlapped schedule (artalk_infer): wav2vec2 of chunk index j+1 on its own low-priority stream beside the AR/VAE body of j
-    int overlap = 0;   // measured at batch 32: +3.5 % end to end, but both sides slow each other: opt-in
-    hipStream_t w2v_stream = nullptr;
-    hipEvent_t w2v_fork = nullptr;
-    std::vector<hipEvent_t> w2v_done;
     hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};   // extra branches of the AR body (run_chunk_body_graphs)
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
     int branches = 0;                 // 0 = automatic (2 for B >= 8), else forced 1/2/4
@@ -394,7 +390,7 @@ void stage_mark(artalk_model* m, hipStream_t s, int bucket) {
     if (!m->profiling || m->in_graph_body) return;
     size_t i;
     next_event(m, s, &i);
-    ((m->w2v_stream && s == m->w2v_stream) ? m->marks_w2v : m->marks).emplace_back(bucket, i);
+    m->marks.emplace_back(bucket, i);
 }
 
 // fuse_ln: the AdaLN-modulated LayerNorm that consumes this GEMM's (768-wide, residual-stream) result.  If the GEMM is split
@@ -419,6 +415,7 @@ void audit(artalk_model* m, const std::string& site, const float* buf, int rows,
 bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse_ln = nullptr) {
     GemmArgs g = g0;
     g.graph_tag = m->in_body ? 1 : 0;
+    g.cus = m->n_cus;
     g.status = m->precision == 1 ? (m->view ? m->view->status : m->ws.status) : nullptr;     // P8 range guard at the producers
     bool split = false;
     if (m->precision == 1 && !g.exact) {
@@ -855,7 +852,8 @@ int ensure_side_streams(artalk_model* m, int n) {
     if (!m->fork_ev) HIPCHK(m, hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming));
     for (int i = 0; i < n && i < 3; ++i) {
         if (m->side_stream[i]) continue;
-        HIPCHK(m, hipStreamCreateWithFlags(&m->side_stream[i], hipStreamNonBlocking));
+        if (m->cu_mask.empty()) HIPCHK(m, hipStreamCreateWithFlags(&m->side_stream[i], hipStreamNonBlocking));
+        else HIPCHK(m, hipExtStreamCreateWithCUMask(&m->side_stream[i], (uint32_t)m->cu_mask.size(), m->cu_mask.data()));
         HIPCHK(m, hipEventCreateWithFlags(&m->join_ev[i], hipEventDisableTiming));
     }
     return ARTALK_OK;
@@ -979,7 +977,6 @@ int reserve(artalk_model* m, int maxB, int maxC) {
     w.ffn_h = F((int64_t)maxB * 100 * 4 * kE); w.logits = F((int64_t)maxB * 100 * 2 * c.code_dim);
     w.splitk_floats = (int64_t)8 << 20; w.splitk = F(w.splitk_floats); w.splitk_b[0] = w.splitk;
     for (int i = 1; i < 4; ++i) w.splitk_b[i] = F(w.splitk_floats);
-    w.splitk_w2v = F(w.splitk_floats);
     w.fhat = F((int64_t)maxB * 100 * c.code_dim); w.nextfeat = F((int64_t)maxB * 100 * c.code_dim);
     w.bits = dalloc_in<uint8_t>(m->ws_allocs, (int64_t)maxB * kNTok * c.code_dim);
     w.hist_bits = dalloc_in<uint8_t>(m->ws_allocs, (int64_t)maxB * kNTok * c.code_dim);
@@ -1050,9 +1047,6 @@ void artalk_destroy(artalk_model* m) {
     for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
-    if (m->w2v_stream) (void)hipStreamDestroy(m->w2v_stream);
-    if (m->w2v_fork) (void)hipEventDestroy(m->w2v_fork);
-    for (auto e : m->w2v_done) (void)hipEventDestroy(e);
     for (int i = 0; i < 3; ++i) {
         if (m->side_stream[i]) (void)hipStreamDestroy(m->side_stream[i]);
         if (m->join_ev[i]) (void)hipEventDestroy(m->join_ev[i]);
@@ -1260,9 +1254,23 @@ int artalk_get_audit(artalk_model* m, char* names_buf, int buf_len, float* value
     return written;
 }
 
-int artalk_set_overlap(artalk_model* m, int enable) {
-    if (!m) return ARTALK_EINVAL;
-    m->overlap = enable ? 1 : 0;
+// Restrict the model to a set of compute units (bit i of mask = CU i / 8 of XCD i % 8 on MI355X): the streams the library creates
+// itself (the second clip group of the AR/VAE body) get the mask, the persistent GEMM kernels size their grids to it.  The caller
+// passes a stream with the same mask to artalk_infer (artalk_op_create_masked_stream).  n_words = 0 clears the mask.
+int artalk_set_cu_mask(artalk_model* m, const uint32_t* mask, int n_words) {
+    if (!m || n_words < 0 || (n_words > 0 && !mask)) return ARTALK_EINVAL;
+    (void)hipSetDevice(m->device); (void)hipDeviceSynchronize();
+    m->cu_mask.assign(mask, mask + n_words);
+    int n = 0;
+    for (uint32_t w : m->cu_mask) n += __builtin_popcount(w);
+    if (n_words > 0 && n < 8) { m->cu_mask.clear(); m->n_cus = 0; return fail(m, ARTALK_EINVAL, "a CU partition needs at least 8 compute units"); }
+    m->n_cus = n;
+    for (int i = 0; i < 3; ++i) {      // side streams are re-created (masked) on demand
+        if (m->side_stream[i]) { (void)hipStreamDestroy(m->side_stream[i]); m->side_stream[i] = nullptr; }
+        if (m->join_ev[i]) { (void)hipEventDestroy(m->join_ev[i]); m->join_ev[i] = nullptr; }
+    }
+    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);      // the GEMM grids were captured for the old CU count
+    m->graphs.clear();
     return ARTALK_OK;
 }
 
@@ -1311,45 +1319,14 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
     stg->used = true;
     m->stream_B = 0;   // the batch call reuses the workspace that holds the streaming history
     HIPCHK(m, hipMemsetAsync(w.status, 0, 4 * sizeof(int), s));
-    m->ev_used = 0; m->dom_events.clear(); m->marks.clear(); m->marks_w2v.clear(); m->prof_stream = s;
-    // Optional overlapped schedule.  wav2vec2 of a chunk does not depend on the AR state, the AR/VAE body of chunk index j needs
-    // only the features of index j, and that body is latency-bound (thousands of small dependent launches).  With the option on
-    // (and >= 8 clips) wav2vec2 runs chunk index by chunk index on its own LOW-priority stream and the body of index j (caller's
-    // stream + the clip-group side stream) runs beside wav2vec2 of index j+1.
-    const bool overlap = m->overlap && m->profiling != 2 && Bj[0] >= 8;     // artalk_set_overlap, default off
-    if (overlap) {
-        if (!m->w2v_stream) {
-            int least = 0, greatest = 0;
-            HIPCHK(m, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIPCHK(m, hipStreamCreateWithPriority(&m->w2v_stream, hipStreamNonBlocking, least));
-            HIPCHK(m, hipEventCreateWithFlags(&m->w2v_fork, hipEventDisableTiming));
-        }
-        while ((int64_t)m->w2v_done.size() < maxch) {
-            hipEvent_t e;
-            HIPCHK(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            m->w2v_done.push_back(e);
-        }
-        HIPCHK(m, hipEventRecord(m->w2v_fork, s));
-        HIPCHK(m, hipStreamWaitEvent(m->w2v_stream, m->w2v_fork, 0));
-        stage_mark(m, m->w2v_stream, PB_OTHER);
-        Workspace wv = m->ws;              // gemm() takes its split-K scratch from the view: the body branches own splitk_b[*]
-        wv.splitk = m->ws.splitk_w2v;
-        m->view = &wv;
-        for (int64_t j = 0; j < maxch; ++j) {
-            for (int c0 = base[j]; c0 < base[j + 1]; c0 += w.G)
-                run_wav2vec(m, audio_dev, c0, std::min(w.G, base[j + 1] - c0), out_w2v_dev, m->w2v_stream);
-            (void)hipEventRecord(m->w2v_done[j], m->w2v_stream);
-        }
-        m->view = nullptr;
-    }
+    m->ev_used = 0; m->dom_events.clear(); m->marks.clear(); m->prof_stream = s;
     stage_mark(m, s, PB_OTHER);
     run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s, encode_style);
     stage_mark(m, s, PB_STYLE);
-    if (!overlap) {
-        for (int c0 = 0; c0 < C; c0 += w.G) {
-            run_wav2vec(m, audio_dev, c0, (int)std::min<int64_t>(w.G, C - c0), out_w2v_dev, s);
-        }
-    }
+    // (wav2vec2 of chunk index j + 1 on a stream of its own beside the AR/VAE body of index j was an option until round 3: with the
+    // persistent one-workgroup-per-CU GEMM kernels, whose workgroups hold a CU's LDS for a whole launch, the body's short kernels wait
+    // behind them - 82 -> 128 ms per step; removed)
+    for (int c0 = 0; c0 < C; c0 += w.G) run_wav2vec(m, audio_dev, c0, (int)std::min<int64_t>(w.G, C - c0), out_w2v_dev, s);
     // initial history: encode + quantise an all-zero motion (app/models.py:86-89)
     launch_enc_input_zero(m->vae_mean, m->vae_std, m->enc_pos, w.enc_in, B, s);
     run_reencode(m, B, s);
@@ -1361,7 +1338,6 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
     const bool graphs = m->use_graphs && m->profiling != 2 && !m->audit;
     for (int64_t j = 0; j < maxch; ++j) {
         const int Bn = Bj[j];
-        if (overlap) HIPCHK(m, hipStreamWaitEvent(s, m->w2v_done[j], 0));
         // AdaLN table of this chunk index for all blocks + head: SiLU(cond) @ [W_0;...;W_11;W_head]^T
         roctxRangePushA("artalk.ar.adaln_table");
         linear(m, w.silu_cond + (long)base[j] * kNTok * kCond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, Bn * kNTok, m->ada_n, kCond,
@@ -1539,11 +1515,10 @@ int artalk_get_profile(artalk_model* m, double* out, int n) {
     HIPCHK(m, hipStreamSynchronize(m->prof_stream));
     auto ms = [&](size_t a, size_t b) { float t = 0.f; (void)hipEventElapsedTime(&t, m->ev_pool[a], m->ev_pool[b]); return (double)t; };
     double r[10] = {0};
-    for (const auto* lane : {&m->marks, &m->marks_w2v})      // overlapped schedule: the wav2vec2 buckets are measured on their own stream
-        for (size_t i = 1; i < lane->size(); ++i) {
-            const int b = (*lane)[i].first;
-            if (b >= 0 && b < 6) r[b] += ms((*lane)[i - 1].second, (*lane)[i].second);
-        }
+    for (size_t i = 1; i < m->marks.size(); ++i) {
+        const int b = m->marks[i].first;
+        if (b >= 0 && b < 6) r[b] += ms(m->marks[i - 1].second, m->marks[i].second);
+    }
     r[6] = ms(m->marks.front().second, m->marks.back().second);
     for (auto& d : m->dom_events) { r[7] += 1.0; r[8] += ms(d.first, d.first + 1); r[9] += d.second; }
     for (int i = 0; i < 10; ++i) out[i] = r[i];
@@ -1654,6 +1629,18 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
     }
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }
+
+// A HIP stream restricted to a set of compute units (hipExtStreamCreateWithCUMask): bit i of the mask = CU (i / 8) of XCD (i % 8) on
+// MI355X (tools/cu_mask_probe.hip), so the low / high 128 bits are the two halves of every XCD.  The stream a model restricted with
+// artalk_set_cu_mask is driven on.
+int artalk_op_create_masked_stream(const uint32_t* mask, int n_words, void** out_stream) {
+    if (!mask || !out_stream || n_words <= 0) return ARTALK_EINVAL;
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask) != hipSuccess) return ARTALK_EHIP;
+    *out_stream = s;
+    return ARTALK_OK;
+}
+int artalk_op_destroy_stream(void* stream) { return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? ARTALK_OK : ARTALK_EHIP; }
 
 int artalk_op_gemm_p8_plan(int M, int N, int K, int residual) {
     GemmArgs g;

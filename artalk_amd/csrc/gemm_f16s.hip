@@ -1682,7 +1682,7 @@ static bool p8_big_ok(const GemmArgs& g) {
 template <int TM>
 static void launch_p8_big(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + 64 * TM - 1) / (64 * TM)) * ((g.N + 255) / 256);
-    const int cus = gemm_p8_cus();
+    const int cus = g.cus > 0 ? g.cus - g.cus % 8 : gemm_p8_cus();
     const size_t lds = 2 * (64 * TM + 256) * 128 + 4096;
     const dim3 grid(tiles < cus ? tiles : cus);
     if (g.R) {
@@ -1723,8 +1723,9 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
         g.res_lds = (res_defer && g.R && !g.gate && !g.c_p8) ? 1 : 0;
         if (g.res_lds) gemm_p8_prepare();
         const size_t lds = 2 * 256 * 128 + (g.res_lds ? 16384 : 0);
-        if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wgp_kernel<1>), dim3(t128 < 512 ? t128 : 512), dim3(256), lds, s, g);
-        else hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < 512 ? t128 : 512), dim3(256), lds, s, g);
+        const int slots = 2 * (g.cus > 0 ? g.cus : gemm_p8_cus());      // two workgroups per CU
+        if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wgp_kernel<1>), dim3(t128 < slots ? t128 : slots), dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < slots ? t128 : slots), dim3(256), lds, s, g);
     }
 }
 // 0: persistent two-workgroup 128x128 kernel, 1 / 2: persistent big-tile kernel with 256x256 / 320x256 tiles.  A cost model picks the
@@ -1738,7 +1739,7 @@ int gemm_p8_variant(const GemmArgs& g) {
     const bool big_ok = p8_big_ok(g);
     if (forced >= 0) return big_ok ? forced : 0;
     if (!big_ok) return 0;
-    const double nk = g.K / 32, cus = gemm_p8_cus();
+    const double nk = g.K / 32, cus = g.cus > 0 ? g.cus - g.cus % 8 : gemm_p8_cus();
     auto big = [&](int TM) {
         const double tiles = (double)((g.M + 64 * TM - 1) / (64 * TM)) * ((g.N + 255) / 256);
         return std::ceil(tiles / cus) * (TM * nk * 0.58 + 3.0 * TM + 2.0);

@@ -66,7 +66,6 @@ class BitwiseARModel:
         self._latched_f32 = False   # an f16x3 call left fp16's range once: the model stays in f32 mode from then on
         self.style_cache_size = 64  # style conditions kept by style clip (set 0 to disable)
         self._style_cache = {}      # key -> (style tensor kept alive, (768,) condition on the device)
-        self._overlap = False       # overlapped wav2vec2 / AR schedule (set_overlap), opt-in
         self._stream = None      # dedicated HIP stream (hipGraph capture is not allowed on the legacy default stream)
         self._h2d_stream = None  # uploads of host clips (inference_batch)
         self.last_aux = {}
@@ -141,8 +140,6 @@ class BitwiseARModel:
         if errors:
             raise RuntimeError("Error(s) in loading state_dict for BitwiseARModel:\n\t" + "\n\t".join(errors[:12]))
         self._loaded = True
-        if self._overlap:
-            capi.lib().artalk_set_overlap(self._h, 1)
         self.set_precision(self._precision)
         return self
 
@@ -220,11 +217,29 @@ class BitwiseARModel:
         tuning knobs (multiples of 16, 0 = keep)."""
         capi.lib().artalk_set_graphs(self._h, int(bool(on)) | (int(branches) << 8) | ((splitk_tiles // 16) << 16) | ((splitk_target // 16) << 24))
 
-    def set_overlap(self, on: bool = True):
-        """Overlapped schedule (default off): wav2vec2 of chunk index j+1 beside the AR/VAE body of chunk index j."""
-        self._overlap = bool(on)
-        if self._h is not None:
-            capi.lib().artalk_set_overlap(self._h, int(self._overlap))
+    def set_cu_mask(self, words: Optional[Sequence[int]]):
+        """Run this model on a subset of the GPU's compute units (``words``: 32-bit mask words, bit i = CU i // 8 of XCD i % 8 on
+        MI355X; None = the whole device): its stream and the library's side streams are created with that mask
+        (hipExtStreamCreateWithCUMask) and the persistent GEMM kernels size their grids to it - e.g. to leave compute units to a
+        renderer running beside the path.  (Two replicas on the two halves of the chip are slower than one on the whole chip:
+        tools/dual_partition_probe.py.)"""
+        if not self._loaded:
+            raise RuntimeError("load_state_dict must be called before set_cu_mask")
+        L = capi.lib()
+        with torch.cuda.device(self._device):
+            torch.cuda.synchronize()
+            if words is None:
+                if L.artalk_set_cu_mask(self._h, None, 0) != capi.OK:
+                    raise RuntimeError("artalk_set_cu_mask failed: " + self._err())
+                self._stream = None
+                return
+            arr = (C.c_uint32 * len(words))(*[int(w) & 0xFFFFFFFF for w in words])
+            if L.artalk_set_cu_mask(self._h, C.cast(arr, C.c_void_p), len(words)) != capi.OK:
+                raise RuntimeError("artalk_set_cu_mask failed: " + self._err())
+            out = C.c_void_p()
+            if L.artalk_op_create_masked_stream(C.cast(arr, C.c_void_p), len(words), C.byref(out)) != capi.OK:
+                raise RuntimeError("hipExtStreamCreateWithCUMask failed")
+            self._stream = torch.cuda.ExternalStream(out.value, device=self._device)
 
     def get_profile(self):
         out = (C.c_double * 10)()

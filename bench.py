@@ -98,7 +98,6 @@ def parse_args(argv=None):
                     help="GEMM arithmetic: exact fp32 MFMA, or fp16 operand-split MFMA with fp32-class accuracy")
     ap.add_argument("--branches", type=int, default=0, help="concurrent clip groups of the AR body (0 = auto)")
     ap.add_argument("--splitk", default="0,0", help="tuning: split-K tile threshold,target workgroups (0 = keep)")
-    ap.add_argument("--overlap", action="store_true", help="overlapped schedule: wav2vec2 of chunk index j+1 beside the AR/VAE body of j")
     ap.add_argument("--synchronous", action="store_true", help="wait for every batch before the next one is enqueued (default: two batches in flight)")
     ap.add_argument("--resident", action="store_true", help="audio already in HBM, codes left in HBM (no PCIe copies in the step)")
     ap.add_argument("--force-collective", action="store_true", help="N = 1: still create the RCCL process group and run the all-gather")
@@ -177,8 +176,6 @@ def main():
     frames_per_clip = model.seq_length(n_samples)
     chunks = B * model.n_chunks(n_samples)
     model.reserve(B, chunks)
-    if args.overlap:
-        model.set_overlap(True)
 
     class ClipList:
         """All world*B clips of the job, clip i = synth_audio(seed i); only the local shard is ever built (pinned host rows)."""
@@ -364,9 +361,6 @@ def main():
                        "collective": ("RCCL all_gather_into_tensor of the codes (backend nccl), world size %d" % world) if collective else None},
             "fps_per_clip": round(value / (B * world), 1),
             "algorithmic_tflops": round(value * GFLOP_PER_FRAME / 1e3, 2),
-            # overlapped schedule: the wav2vec2 buckets are measured on their own stream and run BESIDE ada/ar of the previous chunk
-            # index, so the buckets add up to more than total_ms; ada_ms includes waiting for the features of its chunk index
-            "schedule": "overlapped (wav2vec2 of chunk index j+1 beside the AR/VAE body of j)" if (args.overlap and B >= 8) else "sequential",
             "stages_ms": {k: round(prof[k], 2) for k in ("style_ms", "w2v_conv_ms", "w2v_encoder_ms", "ada_ms", "ar_ms", "vae_ms", "total_ms")},
             "roofline": roofline,
             "parity": parity,

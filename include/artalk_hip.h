@@ -162,10 +162,12 @@ int artalk_set_graphs(artalk_model* m, int enable);
  * names NUL-separated, values[i] the maximum seen at site i since the audit was switched on (tools/p8_headroom.py). */
 int artalk_set_audit(artalk_model* m, int enable);
 int artalk_get_audit(artalk_model* m, char* names_buf, int buf_len, float* values, int max_n);
-/* Overlapped schedule of artalk_infer (default 0 = off; when on, used from 8 clips up): wav2vec2 runs chunk index by chunk
- * index on a low-priority stream of the library while the latency-bound AR/VAE body of the previous chunk index runs on the
- * caller's stream.  Measured +3.5 % at batch 32 (both sides slow each other down); 0 = all of wav2vec2 first. */
-int artalk_set_overlap(artalk_model* m, int enable);
+/* Restrict the model to a set of compute units: bit i of mask[0 .. n_words) = CU i / 8 of XCD i % 8 on MI355X.  The library's own
+ * streams get the mask and its persistent kernels size their grids to it; the caller passes a stream created with the same mask
+ * (artalk_op_create_masked_stream) to artalk_infer - e.g. to leave compute units to a renderer running beside the path.  (Two
+ * replicas of the path on the two halves of the chip measured 18 % BELOW one replica on the whole chip: tools/dual_partition_probe.py,
+ * DESIGN.md section 6.)  n_words = 0 clears it. */
+int artalk_set_cu_mask(artalk_model* m, const uint32_t* mask, int n_words);
 
 /* ---- single-kernel entry points for the parity tests (device pointers, row-major f32) ---- */
 /* C[M,N] = R + gate * act(A[M,K] W[N,K]^T + bias); act: 0 none, 1 gelu(erf), 2 gelu(tanh), 3 leaky_relu(0.2). K % 32 == 0 */
@@ -187,6 +189,10 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
  * operands in P8 and no forced configuration (what the model path calls): 7 / 12 = gemm_p8_big_kernel with 256x256 / 320x256 tiles,
  * 8 = gemm_p8_2wgp_kernel; force_cfg 99 of artalk_op_gemm_f16s_packed launches exactly that choice */
 int artalk_op_gemm_p8_plan(int M, int N, int K, int residual);
+/* a HIP stream restricted to the compute units whose bits are set in mask[0 .. n_words) (hipExtStreamCreateWithCUMask; on MI355X bit i =
+ * CU i / 8 of XCD i % 8): the stream a model with artalk_set_cu_mask is driven on */
+int artalk_op_create_masked_stream(const uint32_t* mask, int n_words, void** out_stream);
+int artalk_op_destroy_stream(void* stream);
 /* y = LN(x)[*w+b][*(1+scale)+shift][act], D in {128,512,768,1024}; act | 0x100 writes y in the P8 split format */
 int artalk_op_layernorm(const float* X, float* Y, const float* w, const float* b, const float* scale, const float* shift,
                         int M, int D, float eps, int act, void* stream);

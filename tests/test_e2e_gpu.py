@@ -76,39 +76,6 @@ def test_batch_equals_single_runs():
     m.set_precision("f32")
 
 
-def test_overlapped_schedule_equals_sequential():
-    """With artalk_set_overlap(1), from 8 clips up artalk_infer runs wav2vec2 chunk index by chunk index on its own stream beside
-    the AR/VAE body of the previous index.  Same arithmetic, different grouping of the wav2vec2 rows: the ragged 9-clip batch must
-    give the same decisions and the same codes to rounding as the sequential schedule, and must be repeatable bit for bit
-    (a race between the two streams would show up here)."""
-    from artalk_amd.synth import synth_audio, synth_style
-    m = get_gpu_model("tiny")
-    cfg, sd = get_state_dict("tiny")
-    mean, std = sd["basic_vae.motion_mean"].numpy(), sd["basic_vae.motion_std"].numpy()
-    secs = [12.0, 10.0, 9.1, 8.0, 6.3, 4.0, 4.0, 2.2, 1.7]
-    audios = [torch.from_numpy(synth_audio(40 + i, s)) for i, s in enumerate(secs)]
-    styles = [torch.from_numpy(synth_style(41 + i, mean, std)) if i % 3 == 0 else None for i in range(len(secs))]
-    try:
-        for precision in ("f16x3", "f32"):
-            m.set_precision(precision)
-            m.set_overlap(False)
-            seq = m.inference_batch(audios, styles, return_aux=True)
-            sbits = [b.clone() for b in m.last_aux["bits"]]
-            sw2v = m.last_aux["w2v"].clone()
-            m.set_overlap(True)
-            ovl = m.inference_batch(audios, styles, return_aux=True)
-            assert (m.last_aux["w2v"] - sw2v).abs().max().item() < 1e-4 * max(1.0, sw2v.abs().max().item())
-            for i in range(len(secs)):
-                assert torch.equal(sbits[i], m.last_aux["bits"][i]), f"clip {i}: decisions differ between the schedules"
-                assert (seq[i] - ovl[i]).abs().max().item() < 1e-5
-            for _ in range(3):
-                again = m.inference_batch(audios, styles)
-                assert all(torch.equal(a, b) for a, b in zip(ovl, again)), "overlapped schedule is not repeatable"
-    finally:
-        m.set_overlap(False)
-        m.set_precision("f32")
-
-
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("case", ["full_10s_s1_style", "full_demo_eng1", "tiny_6p3s_s2"])
 def test_streaming_against_reference_golden(case, precision):

@@ -235,3 +235,30 @@ def test_strict_state_dict_errors():
         BitwiseARModel(cfg).to("cuda").load_state_dict(bad)
     with pytest.raises(RuntimeError, match="before inference"):
         BitwiseARModel(cfg).to("cuda").inference_batch([torch.zeros(16000)])
+
+
+def test_cu_partition_gives_the_same_results():
+    """A model restricted to half of the compute units (artalk_set_cu_mask: its own stream, the library's side streams and the grids
+    of the persistent GEMM kernels follow the mask) makes the same decisions and - the persistent kernels' tile walk changes no
+    summation order - the same codes as on the whole chip."""
+    from artalk_amd.model import BitwiseARModel
+    from artalk_amd.synth import synth_audio
+    cfg, sd = get_state_dict("tiny")
+    audios = [torch.from_numpy(synth_audio(500 + i, 9.0)) for i in range(12)]       # 12 clips x 3 chunks: large-grid GEMMs + two clip groups
+    m = BitwiseARModel(cfg).eval().to("cuda")
+    m.load_state_dict(sd, strict=True)
+    m.set_precision("f16x3")
+    want = [o.cpu() for o in m.inference_batch(audios, return_aux=True)]
+    wbits = [b.cpu() for b in m.last_aux["bits"]]
+    m.set_cu_mask([0xFFFFFFFF] * 4 + [0] * 4)
+    got = [o.cpu() for o in m.inference_batch(audios, return_aux=True)]
+    gbits = [b.cpu() for b in m.last_aux["bits"]]
+    assert m.status() == 0
+    for a, b in zip(gbits, wbits):
+        assert torch.equal(a, b)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    m.set_cu_mask(None)
+    again = [o.cpu() for o in m.inference_batch(audios)]
+    for a, b in zip(again, want):
+        assert torch.equal(a, b)

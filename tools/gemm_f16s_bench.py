@@ -22,6 +22,9 @@ for _M in (8192, 16384):
     SHAPES += [(f"q{_M} qkv", _M, 3072, 1024), (f"q{_M} out", _M, 1024, 1024), (f"q{_M} ff1", _M, 4096, 1024), (f"q{_M} ff2", _M, 1024, 4096)]
 variants = [(1, 1), (7, 1), (8, 1), (99, 1)]   # (cfg, A packed): 0/1 register-staged 128x128 / 64x64; LDS-DMA kernels: 7 256x256, 8 persistent
                                                 # two-workgroup 128x128, 99 the dispatch's own choice; small-grid 64x64: 20 (4 stages), 23 (8), 24 (5); cfg | S << 8 = split-K S (20, 23, 24)
+# one-round launches of the 320x256 kernel on 30 / 60 / 120 / 240 of the 256 CUs (same work per CU): is the per-CU rate load-dependent?
+for _M in (2400, 4800, 9600, 19200):
+    SHAPES += [(f"p{_M} ff2", _M, 1024, 4096)]
 only = os.environ.get("GEMM_ONLY")
 if only:
     SHAPES = [x for x in SHAPES if x[0] in only.split(",") or any(o.endswith("*") and x[0].startswith(o[:-1]) for o in only.split(","))]
