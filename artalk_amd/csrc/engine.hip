@@ -458,6 +458,10 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
                 if (cfg == 28 && S == 1) g.force_cfg = 28;
             }
             if (S > 1) { g.splitk = S; g.partial = cw.splitk; if (g.force_cfg < 0) g.force_cfg = cfg; }
+            // weights of the narrowest steps (levels 0 and 1) are read once per launch by a handful of workgroups: fetched with the
+            // non-temporal policy they do not displace the resident history (A/B, cold weights: -0.2..-0.5 us of 8..16 us at M <= 80,
+            // +0.4 us at M = 400, where several row tiles re-read each weight tile through L2)
+            if (g.M <= 160) g.w_nt = 1;
         } else if (tiles < lim) {
             int S = std::min(std::min(g.K / 64, (tgt + tiles - 1) / tiles), 16);
             while (S > 1 && (int64_t)S * g.M * g.N > cw.splitk_floats) --S;
@@ -1605,6 +1609,7 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
         if (force_cfg == 17) { g.partial = (float*)bias; g.bias = nullptr; }     // (17: gemm_p8_256_kernel with stamps)   // timing build: `bias` carries the stamp buffer (8 x u64 per tile)
         if (force_cfg != 99 && (force_cfg & 0xff) >= 20) {     // 20 / 23 / 24: small-grid LDS-DMA kernel; bits 8-15: split-K factor (slabs in a temporary)
             g.force_cfg = force_cfg & 0xff;
+            g.w_nt = (force_cfg >> 16) & 1;      // tuning: bit 16 = non-temporal weight pieces
             const int S = (force_cfg >> 8) & 0xff;
             static float* part = nullptr;       // tuning/test scratch, grown on demand and kept (never used by the model path)
             static size_t part_cap = 0;

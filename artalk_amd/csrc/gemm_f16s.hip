@@ -1273,11 +1273,16 @@ __global__ __launch_bounds__(256) void gemm_p8_sm_kernel(const GemmArgs g) {
         const int gn = min(n0 + rw, g.N - 1);
         src[APIECES + q] = reinterpret_cast<const unsigned char*>(g.Wp) + ((long)gn * g.ldw + (long)kt0 * BK) * 4 + ((pchunk ^ ((rw >> 1) & 7)) << 4);
     }
+    const bool w_nt = g.w_nt != 0;      // (tuning) weight pieces with the non-temporal cache policy: they are read once per launch
     auto issue_piece = [&](int q, int kt, int buf) {
         unsigned char* dst = smem_p8 + buf * STAGE_BYTES +
                              (q < APIECES ? (wave * APIECES + q) * 1024 : BM * 128 + (wave * WPIECES + q - APIECES) * 1024);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (long)kt * (BK * 4)),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        if (q >= APIECES && w_nt)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (long)kt * (BK * 4)),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (long)kt * (BK * 4)),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
 
     const int wm = wave >> 1, wn = wave & 1;

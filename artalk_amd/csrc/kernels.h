@@ -51,6 +51,7 @@ struct GemmArgs {
     // One launch then computes the same input through many layers' weights (the history K/V of all 12 AR blocks).
     int ngrp = 0; long grpW = 0, grpB = 0, grpC = 0;
     int res_lds = 0;     // persistent kernel: 16 KiB of LDS behind the two stages are there for the deferred residual tiles (launch_gemm_p8)
+    int w_nt = 0;        // (tuning) small-grid kernel: weight pieces fetched with the non-temporal cache policy
     int cus = 0;         // compute units the launch may use (0 = the whole device): grid of the one-workgroup-per-CU persistent kernels when the model runs on a CU partition
     int force_cfg = -1;  // >= 0: tile configuration override (tuning/tests)
     int graph_tag = 0;   // 1 for launches inside the captured AR/VAE body (separate kernel symbol, same code)

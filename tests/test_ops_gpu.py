@@ -174,6 +174,36 @@ def _unpack_p8(t_i32, scale=16.0):
     return ((h[:, :, 0, :] + h[:, :, 1, :]) / scale).reshape(M, K)
 
 
+@pytest.mark.parametrize("M", [2560, 1000])
+def test_gemm_p8_large_grid_kernels_p8_gelu_epilogue(M):
+    """The epilogue the encoder's FFN-in GEMM uses - bias, GELU(erf), result written in the P8 split format - on every large-grid
+    kernel (persistent 256x256 / 320x256 tiles, the non-persistent 256x256 kernel, persistent 128x128): unpacked against float64,
+    and bit-identical across the kernels.  M = 1000 leaves edge tiles whose rows beyond M must not be stored."""
+    capi, L = _lib()
+    N, K = 1024, 512
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    ref = F.gelu(A.double() @ W.double().t() + bias.double())
+    dA, dW, db = _dev(A), _dev(W), _dev(bias)
+    Ap = torch.empty(M, K, dtype=torch.int32, device="cuda")
+    Wp = torch.empty(N, K, dtype=torch.int32, device="cuda")
+    assert L.artalk_op_pack_split(_p(dA), _p(Ap), M * K, 0, None) == 0 and L.artalk_op_pack_split(_p(dW), _p(Wp), N * K, 1, None) == 0
+    outs = []
+    for cfg in (7, 12, 13, 8):
+        out = torch.full((M + 64, N), 0x7fc00000, dtype=torch.int32, device="cuda")      # canary rows behind the result
+        assert L.artalk_op_gemm_f16s_packed(_p(Ap), 1, K, _p(Wp), _p(db), _p(out), M, N, K, 0x101, cfg, None) == 0
+        torch.cuda.synchronize()
+        assert bool((out[M:] == 0x7fc00000).all()), f"cfg {cfg} stored rows beyond M"
+        got = _unpack_p8(out[:M])
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-6, (cfg, err)
+        outs.append(out[:M].cpu())
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+
+
 @pytest.mark.parametrize("act,approx", [(1, "none"), (2, "tanh")])
 def test_gelu_activations_accuracy(act, approx):
     """The branch-free GELUs of common.h (erf form: x * Phi(x) through log2(erfc) as one polynomial + v_exp_f32; tanh form through
