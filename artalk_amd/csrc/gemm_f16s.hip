@@ -583,9 +583,11 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#ifndef BIG_ABL_NOLDS
         read_b(sb, 0);
         ah[0] = lds_read128<0>(a_off[0] + sb);
         al[0] = lds_read128<0>(a_off[1] + sb);
+#endif
     };
     // One K step out of ring buffer `buf`; its top() has run.  The pieces of K tile kt_issue of the tile `src` points at go into the
     // other buffer meanwhile, one per two MFMAs - in EVERY step, so that the step is straight-line code (ONE copy serves the whole
@@ -600,9 +602,11 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
             constexpr int u = decltype(u_tag)::value, kb = u / TM, i = u % TM, sl = u & 1;
             if constexpr (u + 1 < NSUB) {       // prefetch the next sub-step's fragments, then wait for everything older than them
                 constexpr int nkb = (u + 1) / TM, ni = (u + 1) % TM, nsl = (u + 1) & 1;
+#ifndef BIG_ABL_NOLDS      // (timing builds, results wrong: BIG_ABL_NOLDS no fragment reads, BIG_ABL_NODMA no DMA pieces, BIG_ABL_ONEPROD one MFMA product of three, BIG_ABL_NOSTORE stores masked)
                 if constexpr (ni == 0) read_b(sb, nkb);
                 ah[nsl] = lds_read128<ni * 4096>((a_off[0] + sb) ^ (nkb << 6));
                 al[nsl] = lds_read128<ni * 4096>((a_off[1] + sb) ^ (nkb << 6));
+#endif
                 if constexpr (ni == 0) wait_lgkmcnt<6>(); else wait_lgkmcnt<2>();
             } else {
                 wait_lgkmcnt<0>();
@@ -613,10 +617,16 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], ah[sl], acc[i][j], 0, 0, 0);
+#ifndef BIG_ABL_ONEPROD
                     else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kb][j], ah[sl], acc[i][j], 0, 0, 0);
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], al[sl], acc[i][j], 0, 0, 0);
+#endif
                     const int piece = u * 3 + t;     // one DMA piece per two MFMAs from the start of the step
+#ifdef BIG_ABL_NODMA
+                    if (false) {
+#else
                     if (j == 1 && piece < NDMA) {
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                         issue_piece(piece, kt_issue, buf ^ 1);
                         __builtin_amdgcn_sched_barrier(0);
@@ -628,6 +638,10 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
 
     int t = blockIdx.x;
     if (t >= ntiles) return;
+#ifdef BIG_ABL_NOLDS
+    read_b(0, 0); read_b(0, 1);
+    ah[0] = lds_read128<0>(a_off[0]); al[0] = lds_read128<0>(a_off[1]); ah[1] = lds_read128<4096>(a_off[0]); al[1] = lds_read128<4096>(a_off[1]);
+#endif
     int m0, n0;
     tile_origin(t, m0, n0);
     set_src(m0, n0);
@@ -663,9 +677,18 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
         // traffic buys a branch-free step.  The last step runs the ring on into the next tile: its stage 0 goes into the buffer of the
         // step before; the very last step of the workgroup re-fetches K tile 0 of its own tile into that (free) buffer.
         top(gs & 1, nk > 1 ? pre0 : 0);      // (nk == 1: stage 0 only, waited for in full)
+#ifdef BIG_PHASE      // timing build (results wrong): the first tile of a workgroup runs a phase-dependent share of its K steps, so the CUs' epilogues stop coinciding
+#ifdef BIG_PHASE_XCD     // the CUs of an XCD stay in phase (they share operand fetches through their L2), the eight XCDs are spread over a tile period
+        const int nk_cur = tile_no == 0 ? max(2, (nk * ((int)(blockIdx.x & 7) + 1)) / 8) : nk;
+#else
+        const int nk_cur = tile_no == 0 ? max(2, (nk * ((int)((blockIdx.x >> 3) % BIG_PHASE) + 1)) / BIG_PHASE) : nk;
+#endif
+#else
+        const int nk_cur = nk;
+#endif
 #pragma nounroll
-        for (int kt = 0; kt < nk; ++kt) {
-            const bool last = kt + 1 == nk;
+        for (int kt = 0; kt < nk_cur; ++kt) {
+            const bool last = kt + 1 == nk_cur;
             if (last && has_next) set_src(nm0, nn0);
             kstep(gs & 1, last ? 0 : kt + 1, !last, kt == 0 ? pre1 + NDMA : 0);
             ++gs;
@@ -706,7 +729,11 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += res[q][e];
             }
+#ifdef BIG_ABL_NOSTORE
+            epilogue_tile32_store<false>(g, g.C, row, n0 + wn * 64 + j * 32, h, acc[i][j], nullptr, row < (g.force_cfg == 12345 ? g.M : -1));
+#else
             epilogue_tile32_store<false>(g, g.C, row, n0 + wn * 64 + j * 32, h, acc[i][j], nullptr, row < g.M);
+#endif
         };
         using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
         // Residual tiles (the encoder's out-projection and FFN-out, x += ... in place; fp32 result): the residual runs of sub-tile s + 1

@@ -438,6 +438,70 @@ __global__ __launch_bounds__(256) void mfma_f16_peak_kernel(float* out, int iter
     if (threadIdx.x == 0) v = (float)((double)(c1 - c0) / (double)(r1 - r0) * 0.1);     // GHz (s_memrealtime ticks at 100 MHz)
     out[blockIdx.x * 256 + threadIdx.x] = v;
 }
+// The same two shapes on operands that CHANGE from MFMA to MFMA, as a GEMM's do: 12 + 8 pseudo-random fp16 fragments in registers
+// (hi-like values of order 1 and lo-like values of order 2^-11, as the split operands are), every MFMA takes another pair.  The
+// constant-operand loops above barely toggle the multipliers' inputs; the clock the chip holds depends on what the pipes switch.
+__device__ __forceinline__ unsigned peak_hash(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+template <int SHAPE>
+__global__ __launch_bounds__(256) void mfma_f16_peak_rnd_kernel(float* out, int iters, float seed) {
+    const int lane = threadIdx.x & 63;
+    pk_h8 a[12], b[8];
+#pragma unroll
+    for (int f = 0; f < 12; ++f)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned hsh = peak_hash((unsigned)(lane * 977 + f * 131 + e * 7 + blockIdx.x * 7919) + (unsigned)(seed * 1000.f));
+            const float v = ((float)(hsh & 0xffff) / 32768.f - 1.f) * (f % 3 == 2 ? 4.8828125e-4f : 1.f);       // every third fragment lo-like
+            a[f][e] = (_Float16)v;
+        }
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned hsh = peak_hash((unsigned)(lane * 331 + f * 1009 + e * 13 + blockIdx.x * 104729 + 5));
+            const float v = ((float)(hsh & 0xffff) / 32768.f - 1.f) * (f & 1 ? 4.8828125e-4f : 1.f) * 0.03f;
+            b[f][e] = (_Float16)v;
+        }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    float sum = 0.f;
+    if (SHAPE == 0) {
+        f32x16 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[(i + 3 * u) & 7], a[(i * 5 + u * 7) % 12], acc[i], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sum += acc[i][e];
+    } else {
+        pk_f4 acc[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { const pk_f4 z = {0.f, 0.f, 0.f, 0.f}; acc[i] = z; }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[(i + 3 * u) & 7], a[(i * 5 + u * 7) % 12], acc[i], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += acc[i][e];
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float v = sum;
+    if (threadIdx.x == 0) v = (float)((double)(c1 - c0) / (double)(r1 - r0) * 0.1);
+    out[blockIdx.x * 256 + threadIdx.x] = v;
+}
 // returns FLOPs issued by one launch; nacc = independent accumulators per wave (1 = one dependent chain, like the 64x64 GEMM);
 // nacc 16 / 17: the fp16 kernels above (32x32x16 / 16x16x32)
 double launch_mfma_f32_peak(float* out, int blocks, int iters, int nacc, hipStream_t s) {
@@ -445,6 +509,11 @@ double launch_mfma_f32_peak(float* out, int blocks, int iters, int nacc, hipStre
         if (nacc == 16) hipLaunchKernelGGL(mfma_f16_peak_kernel<0>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
         else hipLaunchKernelGGL(mfma_f16_peak_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
         // per iteration and wave: 32 MFMAs of 32x32x16 (32768 flops each) or 64 of 16x16x32 (16384 flops each)
+        return (double)blocks * 4 * iters * 32.0 * (32.0 * 32 * 16 * 2);
+    }
+    if (nacc == 18 || nacc == 19) {      // the fp16 shapes on changing pseudo-random operands
+        if (nacc == 18) hipLaunchKernelGGL(mfma_f16_peak_rnd_kernel<0>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
+        else hipLaunchKernelGGL(mfma_f16_peak_rnd_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
         return (double)blocks * 4 * iters * 32.0 * (32.0 * 32 * 16 * 2);
     }
     if (nacc == 1) hipLaunchKernelGGL(mfma_f32_peak_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);

@@ -465,23 +465,30 @@ class BitwiseARModel:
                         for pos, i in enumerate(order):      # host clips (pinned or not) go straight into their row: one H2D copy each
                             audio_pad[pos, :n_samples[i]].copy_(audios[i], non_blocking=True)
             self._stream.wait_stream(stage)
-            self._stream.wait_stream(caller)
             style_t, has = self._style_rows(style_motions, order, B)
-            out = torch.zeros(B, maxch * 100, self.cfg.motion_dim, dtype=torch.float32, device=dev)   # zeros: rows past a clip's last chunk
-            bits = hist = w2v = None
-            if return_aux:
-                bits = torch.zeros(B, maxch, 181, 32, dtype=torch.uint8, device=dev)
-                hist = torch.zeros(B, maxch + 1, 181, 32, dtype=torch.uint8, device=dev)
-                w2v = torch.zeros(total, 199, self.cfg.cond_dim, dtype=torch.float32, device=dev)
+            # The call's stream waits for the caller's stream only when an input comes from it (device clips, style clips).  With host
+            # clips and no style the call depends on its own staging stream alone: in a serving loop the caller's stream still holds the
+            # previous batch's post-processing (its download, say), which this batch's kernels have no reason to queue behind.
+            if not on_host or style_t is not None:
+                self._stream.wait_stream(caller)
+            with torch.cuda.stream(self._stream):      # results are allocated and cleared on the call's stream, the caller's stream joins below
+                out = torch.zeros(B, maxch * 100, self.cfg.motion_dim, dtype=torch.float32, device=dev)   # zeros: rows past a clip's last chunk
+                bits = hist = w2v = None
+                if return_aux:
+                    bits = torch.zeros(B, maxch, 181, 32, dtype=torch.uint8, device=dev)
+                    hist = torch.zeros(B, maxch + 1, 181, 32, dtype=torch.uint8, device=dev)
+                    w2v = torch.zeros(total, 199, self.cfg.cond_dim, dtype=torch.float32, device=dev)
             nch_sorted = (C.c_int64 * B)(*[nch[i] for i in order])
-            self._stream.wait_stream(caller)
             rc = L.artalk_infer(self._h, capi.ptr(audio_pad), audio_pad.stride(0), nch_sorted, B, capi.ptr(style_t),
                                 C.cast(has, C.c_void_p) if has is not None else None, capi.ptr(out), out.stride(0),
                                 capi.ptr(bits), capi.ptr(hist), capi.ptr(w2v), C.c_void_p(self._stream.cuda_stream))
             caller.wait_stream(self._stream)
-            for t in (audio_pad, style_t, out, bits, hist, w2v):
+            for t in (audio_pad, style_t):
                 if t is not None:
                     t.record_stream(self._stream)
+            for t in (out, bits, hist, w2v):           # allocated on the call's stream, read by the caller's from here on
+                if t is not None:
+                    t.record_stream(caller)
             if rc != capi.OK:
                 raise RuntimeError("artalk_infer failed ({}): {}".format(rc, self._err()))
             if check and self._precision == "f16x3" and self.check_finite and self.status() != 0:

@@ -32,7 +32,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything i
 GFLOP_PER_FRAME = 2.159          # algorithmic work with KV cache, BASELINE.md section 3
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
-SUSTAINED_F16_MFMA_TFLOPS = 1780.0   # measured: register-only v_mfma_f32_32x32x16_f16 loop on non-trivial data holds a 1.75 GHz clock (profiles/r02_mfma_f16_peak.log)
+SUSTAINED_F16_MFMA_TFLOPS = 1745.0   # measured: register-only v_mfma_f32_32x32x16_f16 loop whose operands change from MFMA to MFMA holds 1.67-1.70 GHz (profiles/r03_mfma_f16_peak.log)
 PMC_TRAFFIC_FILE = "profiles/r03_pmc_traffic.json"      # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
 MODES = {
     # precision -> (dtype string, dominant kernel symbol prefix in the PMC file, description, peak TF/s of ALGORITHMIC flops, note)
@@ -102,6 +102,8 @@ def parse_args(argv=None):
     ap.add_argument("--resident", action="store_true", help="audio already in HBM, codes left in HBM (no PCIe copies in the step)")
     ap.add_argument("--force-collective", action="store_true", help="N = 1: still create the RCCL process group and run the all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--io-probe", default="", choices=["", "h2d", "d2h"], help="(diagnosis) keep only the upload or only the download of the step's PCIe copies")
+    ap.add_argument("--trace-host", action="store_true", help="log the host time of every submit / finish of the timed loop")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra (untimed) f32-mode and resident measurements")
     ap.add_argument("--cpu-clips", type=int, default=12)
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched N > 1 run (0 = pick a free one)")
@@ -199,7 +201,7 @@ def main():
     state = {"resident": args.resident, "pipelined": not args.synchronous, "k": 0, "last_host": 0}
 
     def infer_fn(audios, styles):
-        src = dev_audio if state["resident"] else audios                         # host tensors: H2D happens inside inference_batch
+        src = dev_audio if (state["resident"] or args.io_probe == "d2h") else audios   # host tensors: H2D happens inside inference_batch
         return model.inference_batch(src, styles, check=not state["pipelined"])
 
     # One step = upload of the 32 clips -> the path -> download of the codes.  As a serving loop would, the default loop keeps TWO
@@ -211,7 +213,7 @@ def main():
         ticket = model.last_ticket()
         local = outs[mine.start:mine.stop] if collective else outs
         ev = None
-        if not state["resident"]:
+        if not state["resident"] and args.io_probe != "h2d":
             slot = state["k"] % 2
             host_outs[slot].copy_(torch.stack(list(local)), non_blocking=True)   # D2H of this rank's codes
             ev = torch.cuda.Event()
@@ -239,7 +241,11 @@ def main():
         t0 = time.perf_counter()
         prev, outs = None, None
         for _ in range(n):
+            if os.environ.get("BENCH_SLEEP_MS"):      # (diagnosis) a host stall in front of every submit: free if a batch is queued ahead
+                time.sleep(float(os.environ["BENCH_SLEEP_MS"]) * 1e-3)
+            h0 = time.perf_counter()
             cur = submit()
+            h1 = time.perf_counter()
             outs = cur[1]
             if prev is not None:
                 finish(prev)
@@ -247,6 +253,8 @@ def main():
                 finish(cur)
                 cur = None
             prev = cur
+            if args.trace_host:      # where the host spends a step: enqueueing (submit) or waiting for the previous batch (finish)
+                log(f"host: submit {1e3 * (h1 - h0):.2f} ms, finish {1e3 * (time.perf_counter() - h1):.2f} ms")
         if prev is not None:
             finish(prev)
         torch.cuda.synchronize()
@@ -341,8 +349,8 @@ def main():
             "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(dom_tflops / peak, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": kdesc, "peak_note": peak_note,
             "frac_of_sustained": (round(dom_tflops / (SUSTAINED_F16_MFMA_TFLOPS / 3.0), 4) if args.precision == "f16x3" else None),
-            "sustained_note": ("a register-only fp16 MFMA loop sustains 1780 TF/s on this chip (clock 1.75 GHz under that load, "
-                               "profiles/r02_mfma_f16_peak.log): 593 TF/s of algorithmic flops for the 3-product split") if args.precision == "f16x3" else None,
+            "sustained_note": ("a register-only fp16 MFMA loop on changing operands sustains 1745 TF/s on this chip (clock 1.67-1.70 GHz under "
+                               "that load, profiles/r03_mfma_f16_peak.log): 582 TF/s of algorithmic flops for the 3-product split") if args.precision == "f16x3" else None,
             "launches": int(prof["dom_launches"]), "avg_launch_ms": round(prof["dom_ms"] / max(prof["dom_launches"], 1), 4),
             "share_of_step_ms": round(prof["dom_ms"], 2),
         }

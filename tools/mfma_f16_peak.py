@@ -8,7 +8,7 @@ L = capi.lib()
 out = torch.empty(4096 * 256, device="cuda")
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 fl = C.c_double()
-for nacc, name in ((16, "32x32x16_f16"), (17, "16x16x32_f16")):
+for nacc, name in ((16, "32x32x16_f16"), (17, "16x16x32_f16"), (18, "32x32x16_f16 changing operands"), (19, "16x16x32_f16 changing operands")):
     for blocks in (256, 512, 1024):
         iters = 40000
         L.artalk_op_mfma_f32_peak(C.c_void_p(out.data_ptr()), blocks, 2000, nacc, C.byref(fl), s)

@@ -116,6 +116,27 @@ def levels(d, out):
     print(open(out).read())
 
 
+def sequence(d, out, which=3):
+    """The launch list of ONE body (the `which`-th ar_begin ... vq_embed span of the trace): start offset, duration, gap to the end
+    of the previous launch, queue, grid, workgroup, LDS and name - to see where a scale step's wall time goes between its kernels."""
+    rows = [r for r in csv.DictReader(open(find(d, "*kernel_trace.csv")))]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    begins = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith("ar_begin_kernel")]
+    i0 = begins[min(which, len(begins) - 1)]
+    t0, prev_end, n_bits = int(rows[i0]["Start_Timestamp"]), None, 0
+    with open(out, "w") as f:
+        f.write("start_us,dur_us,gap_us,queue,grid,wg,lds,kernel\n")
+        for r in rows[i0:]:
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            gap = (s - prev_end) / 1e3 if prev_end is not None else 0.0
+            f.write(f"{(s - t0) / 1e3:.1f},{(e - s) / 1e3:.1f},{gap:.1f},{r.get('Queue_Id', '')},{r.get('Grid_Size_X', '')},{r.get('Workgroup_Size_X', '')},"
+                    f"{r.get('LDS_Block_Size', '')},{short(r['Kernel_Name'])}\n")
+            prev_end = max(prev_end or 0, e)
+            n_bits += 1
+            if n_bits > 1 and (short(r["Kernel_Name"]).startswith("ar_begin_kernel") or n_bits > 900):      # the next body starts
+                break
+
+
 def markers(d, out):
     """rocprofv3 --marker-trace: host-side roctx ranges of the path (artalk.* : enqueue time of each kernel group)."""
     agg = collections.defaultdict(lambda: [0, 0.0])
@@ -162,6 +183,8 @@ if __name__ == "__main__":
         markers(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "levels":
         levels(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "sequence":
+        sequence(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "shapes":
         shapes(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "stats":
