@@ -40,3 +40,21 @@ if len(conv) >= 3:
     for s, e, q, st, n in full[i0:i1 + 3]:
         print(f"  t={(s - t0) / 1e6:9.3f} ms dur {(e - s) / 1e3:7.1f} us  since prev end {((s - prev_end) / 1e3 if prev_end else 0):7.1f} us  queue {q} stream {st}  {n}")
         prev_end = e if prev_end is None else max(prev_end, e)
+# join bubbles of the AR/VAE body: at every copy of a chunk index's motion (copyBufferRectAligned, issued behind the join of the two
+# clip groups' graphs) the end of the last kernel of either group's stream before it - the difference is time one group ran alone
+kern = [x for x in full if "rocclr" not in x[4] and "at::native" not in x[4]]
+joins = [x for x in full if "copyBufferRectAligned" in x[4]]
+print("\njoin bubbles (us): end of group A's last kernel, of group B's, before each motion copy")
+import bisect
+starts = [x[0] for x in kern]
+for jx in joins[-9:]:
+    i = bisect.bisect_left(starts, jx[0])
+    last = {}
+    for x in reversed(kern[max(0, i - 400):i]):
+        if x[3] not in last:
+            last[x[3]] = x
+        if len(last) == 2:
+            break
+    if len(last) == 2:
+        (sa, xa), (sb, xb) = sorted(last.items())
+        print(f"  t={(jx[0] - t0) / 1e6:9.3f} ms  stream {sa} ended {(jx[0] - xa[1]) / 1e3:8.1f} us before the copy ({xa[4][:40]}), stream {sb} {(jx[0] - xb[1]) / 1e3:8.1f} us ({xb[4][:40]})")
