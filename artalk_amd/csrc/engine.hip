@@ -1616,11 +1616,12 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
             if (S > 1) {
                 const size_t need = (size_t)S * M * N * 4;
                 if (need > part_cap) {
-                    (void)hipDeviceSynchronize();
-                    if (part) (void)hipFree(part);
-                    part = nullptr; part_cap = 0;
-                    if (hipMalloc(&part, need) != hipSuccess) return ARTALK_EHIP;
-                    part_cap = need;
+                    // a smaller scratch is NOT freed: graphs captured from earlier calls (tools/gemm_f16s_bench.py replays one per variant)
+                    // still write to it - freeing it turned their replay into a memory fault.  At least 64 MB, so that it rarely grows.
+                    const size_t cap = std::max(need, (size_t)64 << 20);
+                    float* fresh = nullptr;
+                    if (hipMalloc(&fresh, cap) != hipSuccess) return ARTALK_EHIP;
+                    part = fresh; part_cap = cap;
                 }
                 g.splitk = S; g.partial = part;
             }
