@@ -1162,9 +1162,13 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_mid_kernel(const GemmArgs g) {
     auto mfma_slot = [&](int sidx, const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
         // term-major order: consecutive MFMAs go to different accumulators.  Weight fragment = A operand: C^T, see epilogue_tile32
         const int t = sidx / (2 * TN), i = (sidx / TN) % 2, j = sidx % TN;
+#ifdef MID_ABL_NOMFMA      // (timing builds, results wrong: MID_ABL_NOMFMA one MFMA of twelve per half step, MID_ABL_NODMA no DMA after the prologue, MID_ABL_NOBAR no barriers)
+        if (sidx == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+#else
         if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
         else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+#endif
     };
     auto mfmas = [&](const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
 #pragma unroll
@@ -1184,14 +1188,20 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_mid_kernel(const GemmArgs g) {
         mfmas(ah0, al0, bh0, bl0);
         __builtin_amdgcn_sched_barrier(0);
         wait_vmcnt<(STAGES - 3) * NDMA>();             // stage kt+1 landed for this wave (stages kt+2 .. kt+S-2 may still fly)
+#ifndef MID_ABL_NOBAR
         __builtin_amdgcn_s_barrier();                  // ... and for every wave; every wave is done with stage kt-1
+#endif
         __builtin_amdgcn_sched_barrier(0);
         read_frags(nbuf, 0, ah0, al0, bh0, bl0);
         wait_lgkmcnt<NRD>();                           // kb=1 fragments of stage kt
 #pragma unroll
         for (int sidx = 0; sidx < NMF; ++sidx) {
             mfma_slot(sidx, ah1, al1, bh1, bl1);
+#ifdef MID_ABL_NODMA
+            if (false) {
+#else
             if (sidx < NDMA) {
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 issue_piece(sidx, kt + STAGES - 1, fbuf);
                 __builtin_amdgcn_sched_barrier(0);
