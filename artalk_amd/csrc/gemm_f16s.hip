@@ -1147,16 +1147,20 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_mid_kernel(const GemmArgs g) {
     auto read_frags = [&](int buf, int kb, f16x8 (&ah)[2], f16x8 (&al)[2], f16x8 (&bh)[TN], f16x8 (&bl)[TN]) {
         const unsigned sb = buf * STAGE_BYTES;
         const unsigned ahp = a_off[kb][0] + sb, alp = a_off[kb][1] + sb, whp = w_off[kb][0] + sb, wlp = w_off[kb][1] + sb;
+#ifndef MID_ABL_NOB      // (timing build: the weight operand neither fetched nor read from LDS after the first K step)
         bh[0] = lds_read128<0>(whp);
-        ah[0] = lds_read128<0>(ahp);
         bl[0] = lds_read128<0>(wlp);
+#endif
+        ah[0] = lds_read128<0>(ahp);
         al[0] = lds_read128<0>(alp);
         ah[1] = lds_read128<4096>(ahp);
         al[1] = lds_read128<4096>(alp);
+#ifndef MID_ABL_NOB
         if constexpr (TN == 2) {
             bh[TN - 1] = lds_read128<4096>(whp);
             bl[TN - 1] = lds_read128<4096>(wlp);
         }
+#endif
     };
     constexpr int NMF = 2 * TN * 3;    // MFMAs per half step
     auto mfma_slot = [&](int sidx, const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[TN], const f16x8 (&bl)[TN]) {
@@ -1179,6 +1183,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_mid_kernel(const GemmArgs g) {
     wait_vmcnt_units<NDMA>(min(STAGES - 2, nk - 1));   // stage 0 landed (the prologue left up to STAGES-2 younger stages in flight)
     __builtin_amdgcn_s_barrier();
     read_frags(0, 0, ah0, al0, bh0, bl0);
+#ifdef MID_ABL_NOB
+    bh0[0] = lds_read128<0>(w_off[0][0]); bl0[0] = lds_read128<0>(w_off[0][1]); bh1[0] = lds_read128<0>(w_off[1][0]); bl1[0] = lds_read128<0>(w_off[1][1]);
+#endif
     int kt = 0, buf = 0;                               // buf = kt % STAGES
     for (; kt + STAGES - 1 < nk; ++kt) {               // steady state: stage kt+S-1 still to be fetched
         const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
@@ -1187,7 +1194,11 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_mid_kernel(const GemmArgs g) {
         wait_lgkmcnt<NRD>();                           // the kb=0 fragments (issued half a step ago) are in; the kb=1 reads fly on
         mfmas(ah0, al0, bh0, bl0);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef MID_ABL_NOB
+        wait_vmcnt<(STAGES - 3) * APIECES>();
+#else
         wait_vmcnt<(STAGES - 3) * NDMA>();             // stage kt+1 landed for this wave (stages kt+2 .. kt+S-2 may still fly)
+#endif
 #ifndef MID_ABL_NOBAR
         __builtin_amdgcn_s_barrier();                  // ... and for every wave; every wave is done with stage kt-1
 #endif
@@ -1199,6 +1210,8 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_mid_kernel(const GemmArgs g) {
             mfma_slot(sidx, ah1, al1, bh1, bl1);
 #ifdef MID_ABL_NODMA
             if (false) {
+#elif defined(MID_ABL_NOB)
+            if (sidx < APIECES) {
 #else
             if (sidx < NDMA) {
 #endif
