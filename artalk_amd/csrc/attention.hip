@@ -795,8 +795,19 @@ __global__ __launch_bounds__(NW * 64) void attention_f16_wide_ar_kernel(const At
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * (NW * 16) + wave * 16;
+    // (clip, head, query part) of this workgroup.  With several query parts per head (the VAE stacks: two) the parts of one head are
+    // put on ONE XCD - the hardware deals workgroups to XCDs by linear id % 8 - because they stage the same K and V rows: heads go
+    // in groups of 8 (one per XCD), the part is the slower index inside a group (as attention_short_kernel does).
+    int b = blockIdx.z, h = blockIdx.y, part = blockIdx.x;
+    if (gridDim.x > 1 && ((gridDim.y * gridDim.z) & 7) == 0) {
+        const int np = gridDim.x, lin = blockIdx.x + np * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int grp = lin / (8 * np), rem = lin - grp * 8 * np;
+        const int pair = grp * 8 + (rem & 7);
+        part = rem >> 3;
+        b = pair / (int)gridDim.y;
+        h = pair - b * (int)gridDim.y;
+    }
+    const int q0 = part * (NW * 16) + wave * 16;
     const int qi = q0 + r;
     const bool qvalid = qi < a.Lq;
     const bool wave_active = q0 < a.Lq;
@@ -856,7 +867,7 @@ __global__ __launch_bounds__(NW * 64) void attention_f16_wide_ar_kernel(const At
     // the 64-query workgroup of attention_f16_kernel this wave's queries belong to decides how far its key loop runs there: the same
     // bound here keeps the block sequence of a query identical; the phase loop runs to the furthest bound of the workgroup's waves
     const int lk_wave = (a.split_q > 0 && min((q0 & ~63) + 63, a.Lq - 1) < a.split_q) ? a.split_k : a.Lk;
-    const int wg_last = min((int)(blockIdx.x + 1) * (NW * 16) - 1, a.Lq - 1);
+    const int wg_last = min((part + 1) * (NW * 16) - 1, a.Lq - 1);
     const int lk_loop = (a.split_q > 0 && wg_last < a.split_q) ? a.split_k : a.Lk;
     float m_run = -INFINITY, l_part = 0.f;
     f32x4 ot[4];
