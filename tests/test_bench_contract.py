@@ -1,0 +1,49 @@
+"""The bench line committed for this round (profiles/r03_bench_line.json, written by `python bench.py` on an MI355X) keeps the
+contract the driver reads: the required keys, a roofline object whose fraction is achieved / peak, a cpu_baseline object, and a value
+that is the whole-job rate of the step time next to it.  No GPU needed: the file is data."""
+import glob
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench_line.json")))
+
+
+@pytest.mark.parametrize("path", LINES[-1:] or [None])
+def test_committed_bench_line_keeps_the_contract(path):
+    assert path is not None, "no profiles/r*_bench_line.json committed"
+    d = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None                       # BASELINE.md holds no published number for this metric
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = clips x frames per clip of one step / step time, over all ranks
+    c = d["config"]
+    rate = d["n_gpus"] * c["clips_per_gpu"] * c["frames_per_clip"] / (d["ms_per_step"] * 1e-3)
+    assert abs(rate - d["value"]) / d["value"] < 2e-3
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 2e-3
+    assert r["traffic"] is None or r["traffic"] > 0
+    b = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in b, k
+    assert b["kind"] in ("reference", "port") and b["unit"] == d["unit"] and b["cores"] >= 1
+    # the parity block the run exits non-zero on: codes within the stated tolerance
+    p = d["parity"]
+    assert p["flame_max_abs_err"] <= p["tolerance"] == 1e-3
+
+
+def test_bench_defaults_are_one_gpu_and_minutes():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                          # defines parse_args / main; runs nothing
+    a = mod.parse_args([])
+    assert a.gpus == 1 and 1 <= a.steps <= 50 and a.warmup >= 1
