@@ -704,15 +704,28 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
                 st[t] = acc;
             }
             float mx = -INFINITY;
+            // the key mask only where a block can hold masked keys: the last block of the sequence, or any block under a split
+            // attention mask (the test is uniform over the workgroup; the values are the same either way)
+            if (kb0 + KB <= a.Lk && a.split_q <= 0) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int kidx = kb0 + t * 16 + 4 * g + j;
-                    const float sv = (kidx < klim) ? st[t][j] * sfix : -INFINITY;
-                    st[t][j] = sv;
-                    mx = fmaxf(mx, sv);
-                }
+                    for (int j = 0; j < 4; ++j) {
+                        const float sv = st[t][j] * sfix;
+                        st[t][j] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int kidx = kb0 + t * 16 + 4 * g + j;
+                        const float sv = (kidx < klim) ? st[t][j] * sfix : -INFINITY;
+                        st[t][j] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
@@ -971,15 +984,26 @@ __global__ __launch_bounds__(NW * 64) void attention_f16_wide_ar_kernel(const At
                 st[t] = acc;
             }
             float mx = -INFINITY;
+            if (kb0 + KB <= a.Lk && a.split_q <= 0) {      // a full block without a split mask: no key to hide (uniform test, same values)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int kidx = kb0 + t * 16 + 4 * g + j;
-                    const float sv = (kidx < klim) ? (QKVP8 ? st[t][j] * sfix : st[t][j]) : -INFINITY;
-                    st[t][j] = sv;
-                    mx = fmaxf(mx, sv);
-                }
+                    for (int j = 0; j < 4; ++j) {
+                        const float sv = QKVP8 ? st[t][j] * sfix : st[t][j];
+                        st[t][j] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int kidx = kb0 + t * 16 + 4 * g + j;
+                        const float sv = (kidx < klim) ? (QKVP8 ? st[t][j] * sfix : st[t][j]) : -INFINITY;
+                        st[t][j] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
