@@ -303,8 +303,7 @@ __global__ __launch_bounds__(BSQ_NT) void bsq_history_kernel(const float* __rest
             float x = 0.f;
             if (ok) x = (pn == T100) ? resid[idx] : area_pool(resid, pn, i, c);
             float ss = x * x;                      // 32 consecutive lanes = one token
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            ss = group_sum<32>(ss);
             const float z = x / fmaxf(sqrtf(ss), 1e-12f);
             const float zhat = (z > 0.f) ? c_hq : -c_hq;
             const float q = z + (zhat - z);

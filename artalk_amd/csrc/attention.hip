@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             for (int c = 0; c < NC; ++c)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ss += qf[c][e] * qf[c][e];
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
+            ss += lane_xor<16>(ss);
+            ss += lane_xor<32>(ss);
             const float den = fmaxf(sqrtf(ss), 1e-12f);
             const float mul = a.qscale[h];
 #pragma unroll
@@ -94,8 +94,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             }
             if (a.l2norm) {
                 float ss = kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2] + kv[3] * kv[3];
-#pragma unroll
-                for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                ss = group_sum<TPR>(ss);
                 const float den = fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) kv[e] = kv[e] / den;
@@ -132,8 +131,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
                 st[t][j] = sv;
                 mx = fmaxf(mx, sv);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, lane_xor<16>(mx));
+        mx = fmaxf(mx, lane_xor<32>(mx));
         const float m_new = fmaxf(m_run, mx);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = expf(m_run - m_safe);
@@ -174,8 +173,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     }
     if (!wave_active) return;
     float l = l_part;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l += lane_xor<16>(l);
+    l += lane_xor<32>(l);
     if (qvalid) {
         const float inv = 1.0f / l;
         float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
@@ -236,8 +235,8 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const AttnArgs a) 
             for (int c = 0; c < NC; ++c)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ss += qf[c][e] * qf[c][e];
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
+            ss += lane_xor<16>(ss);
+            ss += lane_xor<32>(ss);
             const float den = fmaxf(sqrtf(ss), 1e-12f);
             const float mul = a.qscale[h];
 #pragma unroll
@@ -282,8 +281,8 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const AttnArgs a) 
             for (int c = 0; c < NC; ++c)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ss += kf[slot][c][e] * kf[slot][c][e];
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
+            ss += lane_xor<16>(ss);
+            ss += lane_xor<32>(ss);
             const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);     // one division per key row; x * (1/n) instead of x / n: 1 ulp
 #pragma unroll
             for (int c = 0; c < NC; ++c) kf[slot][c] *= inv;
@@ -300,8 +299,8 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const AttnArgs a) 
             st[j] = sv;
             mx = fmaxf(mx, sv);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, lane_xor<16>(mx));
+        mx = fmaxf(mx, lane_xor<32>(mx));
         const float m_new = fmaxf(m_run, mx);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = expf(m_run - m_safe);
@@ -330,8 +329,8 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const AttnArgs a) 
         t += 4;
     }
     float l = l_part;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l += lane_xor<16>(l);
+    l += lane_xor<32>(l);
     // ---- merge the four waves' partial results: ot[dd][reg] = O[query r][d = NDT*(4g+reg) + dd] ----
     if (g == 0) { Ms[wave][r] = m_run; Ls[wave][r] = l; }
 #pragma unroll
@@ -423,8 +422,8 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ss += x[kb][u][e] * x[kb][u][e];
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
+            ss += lane_xor<16>(ss);
+            ss += lane_xor<32>(ss);
             const float den = fmaxf(sqrtf(ss), 1e-12f);
             const float mul = a.qscale[h];
 #pragma unroll
@@ -491,8 +490,7 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
             }
             if (a.l2norm) {
                 float ss = kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2] + kv[3] * kv[3];
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                ss = group_sum<16>(ss);
                 const float den = fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) kv[e] = kv[e] / den;
@@ -536,8 +534,8 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
                 st[t][j] = sv;
                 mx = fmaxf(mx, sv);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, lane_xor<16>(mx));
+        mx = fmaxf(mx, lane_xor<32>(mx));
         const float m_new = fmaxf(m_run, mx);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = FASTEXP ? __expf(m_run - m_safe) : expf(m_run - m_safe);
@@ -585,8 +583,8 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
     }
     if (!wave_active) return;
     float l = l_part;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l += lane_xor<16>(l);
+    l += lane_xor<32>(l);
     if (qvalid) {
         const float inv = QKVP8 ? 1.0f / (l * kActScale) : 1.0f / l;      // P8 values carry x16
         float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
@@ -726,8 +724,8 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
                         mx = fmaxf(mx, sv);
                     }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, lane_xor<16>(mx));
+            mx = fmaxf(mx, lane_xor<32>(mx));
             const float m_new = fmaxf(m_run, mx);
             const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = FASTEXP ? __expf(m_run - m_safe) : expf(m_run - m_safe);
@@ -774,8 +772,8 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
             }
         }
         float l = l_part;
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l += lane_xor<16>(l);
+        l += lane_xor<32>(l);
         if (qvalid) {
             const float inv = 1.0f / (l * kActScale);      // P8 values carry x16
             float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
@@ -855,8 +853,8 @@ __global__ __launch_bounds__(NW * 64) void attention_f16_wide_ar_kernel(const At
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ss += x[kb][u][e] * x[kb][u][e];
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
+            ss += lane_xor<16>(ss);
+            ss += lane_xor<32>(ss);
             const float den = fmaxf(sqrtf(ss), 1e-12f);
             const float mul = a.qscale[h];
 #pragma unroll
@@ -944,8 +942,7 @@ __global__ __launch_bounds__(NW * 64) void attention_f16_wide_ar_kernel(const At
                 f32x4 kx = kv[i];
                 if (a.l2norm) {
                     float ss = kx[0] * kx[0] + kx[1] * kx[1] + kx[2] * kx[2] + kx[3] * kx[3];
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                    ss = group_sum<16>(ss);
                     const float den = fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) kx[e] = kx[e] / den;
@@ -1004,8 +1001,8 @@ __global__ __launch_bounds__(NW * 64) void attention_f16_wide_ar_kernel(const At
                         mx = fmaxf(mx, sv);
                     }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, lane_xor<16>(mx));
+            mx = fmaxf(mx, lane_xor<32>(mx));
             const float m_new = fmaxf(m_run, mx);
             const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = FASTEXP ? __expf(m_run - m_safe) : expf(m_run - m_safe);
@@ -1054,8 +1051,8 @@ __global__ __launch_bounds__(NW * 64) void attention_f16_wide_ar_kernel(const At
     }
     if (!wave_active) return;
     float l = l_part;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l += lane_xor<16>(l);
+    l += lane_xor<32>(l);
     if (qvalid) {
         const float inv = QKVP8 ? 1.0f / (l * kActScale) : 1.0f / l;      // P8 values carry x16
         float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;

@@ -490,15 +490,51 @@ __device__ __forceinline__ void partial_tile32(const GemmArgs& g, float* P, int 
     }
 }
 
+// The value of lane (lane ^ MASK), MASK a power of two: what __shfl_xor(v, MASK, 64) returns, without the LDS crossbar.  hipcc turns
+// __shfl_xor into ds_bpermute_b32 (an LDS-pipe instruction: address VALU + ~100 cycles + an lgkmcnt wait, and the butterflies are
+// dependent chains of them); here masks 1 / 2 / 8 are one DPP move (quad permutes, row rotate by 8), 4 is two (half-row mirror, then
+// quad reverse: 7 - l = l ^ 7, ^ 3 = l ^ 4), 16 / 32 are gfx950's v_permlane16_swap / v_permlane32_swap of the value with itself plus a
+// select.  Same lanes paired in the same order as before: sums and maxima keep their bits.
+template <int MASK>
+__device__ __forceinline__ float lane_xor(float v) {
+    static_assert(MASK == 1 || MASK == 2 || MASK == 4 || MASK == 8 || MASK == 16 || MASK == 32, "power of two below 64");
+    const int u = __builtin_bit_cast(int, v);
+    if constexpr (MASK == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(u, u, 0xB1, 0xf, 0xf, false));          // quad_perm [1,0,3,2]
+    else if constexpr (MASK == 2) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(u, u, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 4) {
+        const int t = __builtin_amdgcn_update_dpp(u, u, 0x141, 0xf, 0xf, false);                                                    // row_half_mirror
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(t, t, 0x1B, 0xf, 0xf, false));                                  // quad_perm [3,2,1,0]
+    } else if constexpr (MASK == 8) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(u, u, 0x128, 0xf, 0xf, false));  // row_ror:8
+    else if constexpr (MASK == 16) {
+        // swap(a = v, b = v): a' = rows [v0, v0, v2, v2], b' = rows [v1, v1, v3, v3]; an even row takes its neighbour from b', an odd one from a'
+        const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+        return __builtin_bit_cast(float, (__lane_id() & 16) ? sw[0] : sw[1]);
+    } else {
+        // swap(a = v, b = v): a' = [v.lo, v.lo], b' = [v.hi, v.hi]
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)u, (unsigned)u, false, false);
+        return __builtin_bit_cast(float, (__lane_id() & 32) ? sw[0] : sw[1]);
+    }
+}
+// sum over aligned groups of G consecutive lanes (G a power of two), butterfly from G / 2 down to 1 (the order of the former
+// `for (o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o)` loops)
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (G >= 64) v += lane_xor<32>(v);
+    if constexpr (G >= 32) v += lane_xor<16>(v);
+    if constexpr (G >= 16) v += lane_xor<8>(v);
+    if constexpr (G >= 8) v += lane_xor<4>(v);
+    if constexpr (G >= 4) v += lane_xor<2>(v);
+    if constexpr (G >= 2) v += lane_xor<1>(v);
+    return v;
+}
 // full-wave (64 lanes) butterfly reductions
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += lane_xor<32>(v); v += lane_xor<16>(v); v += lane_xor<8>(v); v += lane_xor<4>(v); v += lane_xor<2>(v); v += lane_xor<1>(v);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, lane_xor<32>(v)); v = fmaxf(v, lane_xor<16>(v)); v = fmaxf(v, lane_xor<8>(v));
+    v = fmaxf(v, lane_xor<4>(v)); v = fmaxf(v, lane_xor<2>(v)); v = fmaxf(v, lane_xor<1>(v));
     return v;
 }
 

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
         const float xv = x[idx];
         float xs[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) xs[k] = __shfl(xv, k, 64);
+        for (int k = 0; k < 10; ++k) xs[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv), k));   // (v_readlane: a scalar, no LDS crossbar)
         f32x2 v[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
