@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 // row-contiguous: 64-byte pieces of a key row for K, whole 256-byte rows for V), the next tile's loads are issued before
 // the current tile's MFMAs, no LDS and no barrier in the loop; the four partial (m, l, O) are merged through LDS at the end.
 template <int HD>
-__global__ __launch_bounds__(256) void attention_short_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attention_short_kernel(const AttnArgs a) {      // (2 blocks per CU: at most 256 registers per wave, which is what makes hipcc keep the MFMA accumulators in VGPRs - with the full 512 it put them in AGPRs and moved them out and back around the softmax and the rescale, 123 v_accvgpr moves and 66 hazard nops per tile pair)
     static_assert(HD == 64, "head dim");
     constexpr int NC = 4, NDT = 4;
     __shared__ __attribute__((aligned(16))) float Os[4][16][HD + 4];
