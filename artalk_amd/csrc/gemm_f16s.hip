@@ -1278,7 +1278,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_mid_kernel(const GemmArgs g) {
 // 23-28 us whatever M was).  Here a 64x64 (or 128x64) tile is fed by the same LDS-DMA ring as the big kernels, STAGES-1 K
 // tiles in flight, 4 waves (2 x 2), split-K over blockIdx.y with the partial slabs of gemm_f32.hip.
 template <int BM, int BN, int STAGES, int TAG>
-__global__ __launch_bounds__(256) void gemm_p8_sm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_p8_sm_kernel(const GemmArgs g) {      // (, 2: a wave capped at 256 registers - hipcc then takes the VGPR form of the MFMAs, no accumulator moves out of AGPRs in the epilogue)
     constexpr int BK = 32;
     constexpr int TM = BM / 64, TN = BN / 64;              // 32x32 MFMA tiles per wave
     constexpr int APIECES = BM / 32, WPIECES = BN / 32;    // 1-KiB DMA pieces per wave per stage
