@@ -20,7 +20,7 @@ namespace artalk {
 // launches (TAG=0: wav2vec2 encoder + AdaLN table, the dominant kernel of the path) form one kernel symbol whose every launch is
 // bracketed by HIP events in bench.py and listed as one row by rocprofv3.
 template <int BM, int BN, int WM, int WN, int BK, int AMODE, int TAG = 0>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int LDS_LD = BK + 4;                 // floats; the +4 pad keeps the ds_read_b128 fragment reads conflict-free
     constexpr int TPR = BK / 4, RPP = 256 / TPR;   // staging: threads per row, rows per pass
     constexpr int NQ = BK / 8;                     // 16-byte chunks of a fragment per lane (lane half h holds k in [h*BK/2, (h+1)*BK/2))
