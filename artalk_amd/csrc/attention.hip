@@ -18,7 +18,7 @@
 namespace artalk {
 
 template <int HD>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
     constexpr int KB = 64;
     constexpr int KLD = HD + 8, VLD = HD + 16;   // V rows: lane r reads NDT consecutive floats (one ds_read_b128 for HD = 64)
     constexpr int NC = HD / 16;    // 16-byte chunks of a q/k row held per lane (chunk index g + 4c)
