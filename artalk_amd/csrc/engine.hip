@@ -110,6 +110,8 @@ struct artalk_model {
     unsigned int* audit_vals = nullptr;            // device, kAuditSlots floats (as bits)
     std::vector<std::string> audit_names;
     std::map<std::string, int> audit_index;
+    // intermediate taps (artalk_set_tap): parity tests compare these device buffers with intermediates captured from the reference
+    float* tap = nullptr; int tap_B = 0, tap_maxch = 0, tap_chunk = 0;
     std::vector<uint32_t> cu_mask;    // artalk_set_cu_mask: the library's own streams are restricted to these compute units
     int n_cus = 0;                    // their number (0 = the whole device): grid of the persistent one-workgroup-per-CU kernels
     int stream_B = 0;                 // streams opened by artalk_stream_begin (history lives in the workspace)
@@ -498,6 +500,17 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
     return fused;
 }
 
+// ---- intermediate taps (include/artalk_hip.h: artalk_set_tap) ----
+// slot (chunk index j, clip position b) of the tap buffer, fields in floats:
+enum { TAP_BLK0_IN = 0, TAP_BLK0_OUT = kNTok * kE, TAP_BLKL_OUT = 2 * kNTok * kE, TAP_PREV_IN = 3 * kNTok * kE,
+       TAP_LOGITS = 4 * kNTok * kE, TAP_DEC_OUT = 4 * kNTok * kE + kNTok * 64, TAP_SLOT = 4 * kNTok * kE + kNTok * 64 + 200 * 106 };
+// copies `rows` x `cols` fp32 values per clip (compact source [B][rows][cols]) to row `row0` of field `field` of the chunk's slots
+void tap_copy(artalk_model* m, int field, int row0, const float* src, int rows, int cols, int B, hipStream_t s) {
+    if (!m->tap || m->in_graph_body || m->tap_chunk >= m->tap_maxch || B > m->tap_B) return;
+    float* dst = m->tap + ((long)m->tap_chunk * m->tap_B) * TAP_SLOT + field + (long)row0 * cols;
+    (void)hipMemcpy2DAsync(dst, (size_t)TAP_SLOT * 4, src, (size_t)rows * cols * 4, (size_t)rows * cols * 4, B, hipMemcpyDeviceToDevice, s);
+}
+
 enum { LF_EXACT = 1, LF_A_P8 = 2, LF_C_P8 = 4 };   // linear() flags: decision-critical (fp32 path) / A is in P8 / write C in P8
 // plain y = act(x W^T + b) [+ R]
 void linear(artalk_model* m, const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N, int K,
@@ -704,6 +717,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
     // format by their producers, which lets every block GEMM use the LDS-DMA kernels (gemm_p8_sm_kernel at these grid sizes)
     const int p8 = m->precision == 1 ? 1 : 0;
     // K/V of the 181 history tokens, once per layer (raw prev tokens, not modulated: app/transformer.py:68-70)
+    tap_copy(m, TAP_PREV_IN, 0, w.prev_in, kNTok, kE, B, s);      // prev_attn_feat + prev_lvl_pos_embed (app/models.py:101, 2nd argument)
     roctxRangePushA("artalk.ar.history_kv");
     if (p8) launch_pack_split(w.prev_in, reinterpret_cast<unsigned int*>(w.prev_in_p8), (long)B * kNTok * kE, false, s, w.status);   // one split for the 12 layers
     audit(m, "ar.history_tokens", p8 ? w.prev_in_p8 : w.prev_in, B * kNTok, kE, kE, p8, s);
@@ -757,6 +771,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
             const float* ada = w.ada + (long)l * 6 * kE;
             float* cache = w.cache + l * cache_l;
             const std::string an = "ar.block" + std::to_string(l);
+            if (l == 0) tap_copy(m, TAP_BLK0_IN, off, w.x, pn, kE, B, s);        // attn_feat entering attn_blocks[0] (app/models.py:100)
             if (!have_ln) launch_layernorm(ln_args(l, 0), s);
             audit(m, an + ".ln1_mod", w.xmod, M, kE, kE, p8, s);
             GemmArgs q;
@@ -784,9 +799,12 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
             f2.gate = ada + kE; f2.ldg = ldada; f2.gmap = amap; f2.R = w.x; f2.ldr = kE; f2.M = M; f2.N = kE; f2.K = 4 * kE; f2.a_packed = p8;
             const LnArgs nn = ln_args(l + 1, 0);               // next block's first norm, or the head's after the last block
             have_ln = gemm(m, f2, s, &nn);
+            if (l == 0) tap_copy(m, TAP_BLK0_OUT, off, w.x, pn, kE, B, s);        // output of attn_blocks[0] (app/transformer.py:43)
+            if (l == c.ar_depth - 1) tap_copy(m, TAP_BLKL_OUT, off, w.x, pn, kE, B, s);   // output of the last block (app/models.py:102)
         }
         if (!have_ln) launch_layernorm(ln_args(c.ar_depth, 0), s);
         linear(m, w.xmod, kE, m->logits_w, m->logits_b, w.logits, 2 * c.code_dim, M, 2 * c.code_dim, kE, ACT_NONE, nullptr, s, LF_EXACT);
+        tap_copy(m, TAP_LOGITS, off, w.logits, pn, 2 * c.code_dim, B, s);          // pred_motion_logits (app/models.py:103), fp32
         launch_ar_bits_next(w.logits, w.bits, w.fhat, w.nextfeat, B, p, s, w.status);
         if (p + 1 < c.n_levels)
             launch_vq_embed(w.nextfeat, m->pn[p + 1], m->vq_w, m->vq_b, m->lvl_pos + (long)m->off[p + 1] * kE, w.x, m->pn[p + 1], 0,
@@ -802,6 +820,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
     run_vae_stack(m, m->dec, B, 200, 100, s);
     audit(m, "vae.decoder.output_head(fp32 A)", w.vh, B * 200, H, H, false, s);
     linear(m, w.vh, H, m->dec.out_w, m->dec.out_b, w.dec_out, c.motion_dim, B * 200, c.motion_dim, H, ACT_NONE, nullptr, s);
+    tap_copy(m, TAP_DEC_OUT, 0, w.dec_out, 200, c.motion_dim, B, s);               // dec_out before unnorm_with_stats (bitwise_vae.py:111)
     launch_dec_finish(w.dec_out, m->vae_mean, m->vae_std, m->enc_pos, w.motion_chunk, 100L * c.motion_dim, 0, w.enc_in, B, s, w.status);
     roctxRangePop();
     // ---- re-encode the generated motion into the next history (app/models.py:111-114) ----
@@ -834,7 +853,7 @@ Workspace clip_view(const artalk_model* m, int b0, int branch) {
 // becomes a fork/join in the hipGraph): one half's GPU-filling step overlaps the other half's latency-bound ones.
 int ensure_side_streams(artalk_model* m, int n);
 int run_chunk_body_split(artalk_model* m, int B, hipStream_t s) {
-    if (B < 8 || m->profiling == 2 || m->branches == 1 || m->audit) { run_chunk_body(m, B, s); return ARTALK_OK; }
+    if (B < 8 || m->profiling == 2 || m->branches == 1 || m->audit || m->tap) { run_chunk_body(m, B, s); return ARTALK_OK; }
     if (int rc = ensure_side_streams(m, 1)) return rc;
     const int B0 = (B + 1) / 2, B1 = B - B0;
     Workspace v0 = clip_view(m, 0, 0), v1 = clip_view(m, B0, 1);
@@ -1258,6 +1277,23 @@ int artalk_get_audit(artalk_model* m, char* names_buf, int buf_len, float* value
     return written;
 }
 
+// Intermediate taps for the parity tests (SURVEY.md 8c "reference-captured intermediates"): while a tap buffer is set, artalk_infer runs
+// the AR/VAE body eagerly as ONE clip group (no graphs) and copies, per chunk index j and clip position b (sorted order), into slot
+// (j * max_batch + b) of `tap_dev`: the layout of artalk_tap_layout().  tap_dev = NULL switches it off.
+int artalk_set_tap(artalk_model* m, float* tap_dev, int max_batch, int max_chunks) {
+    if (!m || max_batch < 0 || max_chunks < 0) return ARTALK_EINVAL;
+    (void)hipSetDevice(m->device); (void)hipDeviceSynchronize();
+    m->tap = tap_dev; m->tap_B = tap_dev ? max_batch : 0; m->tap_maxch = tap_dev ? max_chunks : 0; m->tap_chunk = 0;
+    return ARTALK_OK;
+}
+// out[0..6] = float offsets of the fields blk0_in, blk0_out, blkL_out, prev_in, logits, dec_out inside a slot, out[6] = floats per slot
+int artalk_tap_layout(int64_t* out, int n) {
+    if (!out || n < 7) return ARTALK_EINVAL;
+    const int64_t v[7] = {TAP_BLK0_IN, TAP_BLK0_OUT, TAP_BLKL_OUT, TAP_PREV_IN, TAP_LOGITS, TAP_DEC_OUT, TAP_SLOT};
+    for (int i = 0; i < 7; ++i) out[i] = v[i];
+    return ARTALK_OK;
+}
+
 // Restrict the model to a set of compute units (bit i of mask = CU i / 8 of XCD i % 8 on MI355X): the streams the library creates
 // itself (the second clip group of the AR/VAE body) get the mask, the persistent GEMM kernels size their grids to it.  The caller
 // passes a stream with the same mask to artalk_infer (artalk_op_create_masked_stream).  n_words = 0 clears the mask.
@@ -1268,6 +1304,8 @@ int artalk_set_cu_mask(artalk_model* m, const uint32_t* mask, int n_words) {
     int n = 0;
     for (uint32_t w : m->cu_mask) n += __builtin_popcount(w);
     if (n_words > 0 && n < 8) { m->cu_mask.clear(); m->n_cus = 0; return fail(m, ARTALK_EINVAL, "a CU partition needs at least 8 compute units"); }
+    int dev_cus = 0;      // mask bits beyond the device's CUs select nothing: the grids must not count them
+    if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, m->device) == hipSuccess && dev_cus > 0) n = std::min(n, dev_cus);
     m->n_cus = n;
     for (int i = 0; i < 3; ++i) {      // side streams are re-created (masked) on demand
         if (m->side_stream[i]) { (void)hipStreamDestroy(m->side_stream[i]); m->side_stream[i] = nullptr; }
@@ -1339,9 +1377,11 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
         HIPCHK(m, hipMemcpy2DAsync(out_hist_bits_dev, (size_t)(maxch + 1) * bits_row, w.hist_bits, bits_row, bits_row, B,
                                    hipMemcpyDeviceToDevice, s));
     stage_mark(m, s, PB_VAE);
-    const bool graphs = m->use_graphs && m->profiling != 2 && !m->audit;
+    const bool graphs = m->use_graphs && m->profiling != 2 && !m->audit && !m->tap;
+    if (m->tap && (B > m->tap_B || maxch > m->tap_maxch)) return fail(m, ARTALK_EINVAL, "the tap buffer (artalk_set_tap) is smaller than this call");
     for (int64_t j = 0; j < maxch; ++j) {
         const int Bn = Bj[j];
+        m->tap_chunk = (int)j;
         // AdaLN table of this chunk index for all blocks + head: SiLU(cond) @ [W_0;...;W_11;W_head]^T
         roctxRangePushA("artalk.ar.adaln_table");
         linear(m, w.silu_cond + (long)base[j] * kNTok * kCond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, Bn * kNTok, m->ada_n, kCond,
@@ -1589,6 +1629,20 @@ int artalk_op_gemm_f16s(const float* A, int64_t lda, const float* W, const float
     return hipGetLastError() == hipSuccess ? ARTALK_OK : ARTALK_EHIP;
 }
 
+// split-K scratch of the tuning entry point below (never used by the model path): the current buffer and the ones it outgrew
+static float* g_op_scratch = nullptr;
+static size_t g_op_scratch_cap = 0;
+static std::vector<float*> g_op_retired;
+// Frees every scratch buffer of artalk_op_gemm_f16s_packed (current and retired).  The caller guarantees that no captured graph
+// that replays such a launch is used afterwards (tools/* destroy their graphs first; pytest calls it at session end).
+int artalk_op_release_scratch(void) {
+    if (hipDeviceSynchronize() != hipSuccess) return ARTALK_EHIP;
+    for (float* p : g_op_retired) (void)hipFree(p);
+    g_op_retired.clear();
+    if (g_op_scratch) (void)hipFree(g_op_scratch);
+    g_op_scratch = nullptr; g_op_scratch_cap = 0;
+    return ARTALK_OK;
+}
 // building blocks for tuning the split GEMM without allocation noise: pack once, then launch on packed operands
 int artalk_op_pack_split(const float* in, void* out_u32, int64_t n, int is_weight, void* stream) {
     if (!in || !out_u32 || n <= 0) return ARTALK_EINVAL;
@@ -1611,19 +1665,19 @@ int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const v
             g.force_cfg = force_cfg & 0xff;
             g.w_nt = (force_cfg >> 16) & 1;      // tuning: bit 16 = non-temporal weight pieces
             const int S = (force_cfg >> 8) & 0xff;
-            static float* part = nullptr;       // tuning/test scratch, grown on demand and kept (never used by the model path)
-            static size_t part_cap = 0;
             if (S > 1) {
                 const size_t need = (size_t)S * M * N * 4;
-                if (need > part_cap) {
-                    // a smaller scratch is NOT freed: graphs captured from earlier calls (tools/gemm_f16s_bench.py replays one per variant)
-                    // still write to it - freeing it turned their replay into a memory fault.  At least 64 MB, so that it rarely grows.
+                if (need > g_op_scratch_cap) {
+                    // a smaller scratch is NOT freed here: graphs captured from earlier calls (tools/gemm_f16s_bench.py replays one per
+                    // variant) still write to it - freeing it turned their replay into a memory fault.  It is RETIRED instead and freed by
+                    // artalk_op_release_scratch(), which the owner of those graphs calls once they are gone.  At least 64 MB, so that it rarely grows.
                     const size_t cap = std::max(need, (size_t)64 << 20);
                     float* fresh = nullptr;
                     if (hipMalloc(&fresh, cap) != hipSuccess) return ARTALK_EHIP;
-                    part = fresh; part_cap = cap;
+                    if (g_op_scratch) g_op_retired.push_back(g_op_scratch);
+                    g_op_scratch = fresh; g_op_scratch_cap = cap;
                 }
-                g.splitk = S; g.partial = part;
+                g.splitk = S; g.partial = g_op_scratch;
             }
             launch_gemm_p8_sm(g, (hipStream_t)stream);
             if (S > 1) launch_splitk_reduce(g, (hipStream_t)stream);

@@ -1728,6 +1728,15 @@ static int gemm_p8_cus() {      // workgroups of the one-per-CU persistent kerne
     }
     return n[dev];
 }
+// CU count of a launch: the partition's (GemmArgs::cus, artalk_set_cu_mask) rounded down to a multiple of 8 and clamped to
+// [8, the device's]: a count of 1..7 would otherwise size a grid of zero workgroups (an invalid launch, and a division by zero
+// in the cost model), one above the device's would put more than one persistent workgroup on a CU.
+static int p8_cus_of(const GemmArgs& g) {
+    const int dev = gemm_p8_cus();
+    if (g.cus <= 0) return dev;
+    const int c = g.cus - g.cus % 8;
+    return c < 8 ? 8 : (c > dev ? dev : c);
+}
 // what gemm_p8_big_kernel's epilogue and 32-bit source offsets need: whole 256-column tiles, the 16-byte epilogue path, no gate, a
 // residual only with an fp32 result and no activation, no column groups, operands below 4 GiB
 static bool p8_big_ok(const GemmArgs& g) {
@@ -1737,7 +1746,7 @@ static bool p8_big_ok(const GemmArgs& g) {
 template <int TM>
 static void launch_p8_big(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + 64 * TM - 1) / (64 * TM)) * ((g.N + 255) / 256);
-    const int cus = g.cus > 0 ? g.cus - g.cus % 8 : gemm_p8_cus();
+    const int cus = p8_cus_of(g);
     const size_t lds = 2 * (64 * TM + 256) * 128 + 4096;
     const dim3 grid(tiles < cus ? tiles : cus);
     if (g.R) {
@@ -1778,7 +1787,7 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
         g.res_lds = (res_defer && g.R && !g.gate && !g.c_p8) ? 1 : 0;
         if (g.res_lds) gemm_p8_prepare();
         const size_t lds = 2 * 256 * 128 + (g.res_lds ? 16384 : 0);
-        const int slots = 2 * (g.cus > 0 ? g.cus : gemm_p8_cus());      // two workgroups per CU
+        const int slots = 2 * p8_cus_of(g);      // two workgroups per CU
         if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wgp_kernel<1>), dim3(t128 < slots ? t128 : slots), dim3(256), lds, s, g);
         else hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < slots ? t128 : slots), dim3(256), lds, s, g);
     }
@@ -1794,7 +1803,7 @@ int gemm_p8_variant(const GemmArgs& g) {
     const bool big_ok = p8_big_ok(g);
     if (forced >= 0) return big_ok ? forced : 0;
     if (!big_ok) return 0;
-    const double nk = g.K / 32, cus = g.cus > 0 ? g.cus - g.cus % 8 : gemm_p8_cus();
+    const double nk = g.K / 32, cus = p8_cus_of(g);
     auto big = [&](int TM) {
         const double tiles = (double)((g.M + 64 * TM - 1) / (64 * TM)) * ((g.N + 255) / 256);
         return std::ceil(tiles / cus) * (TM * nk * 0.58 + 3.0 * TM + 2.0);

@@ -70,6 +70,12 @@ def gather_clips(local: Sequence[torch.Tensor], max_frames: int, group=None, for
     if all_lengths is not None:
         assert len(all_lengths) == world * n, "all_lengths must cover every (padded) slot of every rank"
         all_len = [int(v) for v in all_lengths]
+        # the host-derived counts slice the gathered buffer: they must be what infer_fn really returned for this rank's slots,
+        # else rows would be truncated (or zero rows returned) silently.  Host ints on both sides: no synchronisation.
+        rank = dist.get_rank(group)
+        for i, t in enumerate(local):
+            assert int(t.shape[0]) == all_len[rank * n + i], (
+                f"rank {rank} slot {i}: infer_fn returned {int(t.shape[0])} frames but the host-derived length is {all_len[rank * n + i]}")
     else:
         lens = torch.tensor([t.shape[0] for t in local], dtype=torch.int64).to(dev)
         all_len = torch.empty(world * n, dtype=torch.int64, device=dev)
@@ -79,7 +85,8 @@ def gather_clips(local: Sequence[torch.Tensor], max_frames: int, group=None, for
 
 
 def run_sharded(infer_fn, audios: Sequence[torch.Tensor], styles=None, gather: bool = True, group=None,
-                max_frames: Optional[int] = None, force_collective: bool = False, lengths: Optional[Sequence[int]] = None):
+                max_frames: Optional[int] = None, force_collective: bool = False, lengths: Optional[Sequence[int]] = None,
+                as_rank: Optional[tuple] = None):
     """Shard ``audios`` over the ranks, run ``infer_fn(list_of_audio, list_of_style)`` on the local shard and
     (optionally) all-gather.  Result order equals input order; shards are padded to equal size with empties.
     ``audios`` only needs ``len()`` and indexing (a lazy sequence may build just the local clips); pass ``lengths`` (frames of
@@ -88,6 +95,13 @@ def run_sharded(infer_fn, audios: Sequence[torch.Tensor], styles=None, gather: b
     for the device (``gather_clips``); with only ``max_frames`` the lengths are exchanged and read back."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if as_rank is not None:
+        # ``as_rank = (r, W)``: compute exactly what rank r of a W-rank job computes - its shard through the same local path - without a
+        # process group (no exchange: ``gather`` must be False).  One GPU can walk a multi-GPU workload shard by shard this way
+        # (tests/test_configs_gpu.py::test_config3_workload_on_one_gpu); it measures nothing about scaling.
+        assert not gather, "as_rank runs one shard locally; there is nothing to gather from"
+        rank, world = int(as_rank[0]), int(as_rank[1])
+        assert 0 <= rank < world
     n = len(audios)
     mine = shard_range(n, rank, world)
     loc_a = [audios[i] for i in mine]

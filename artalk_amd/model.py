@@ -226,8 +226,16 @@ class BitwiseARModel:
         if not self._loaded:
             raise RuntimeError("load_state_dict must be called before set_cu_mask")
         L = capi.lib()
+        self.stream_end()       # a streaming session runs on the stream that is replaced below (and the side streams are re-created)
         with torch.cuda.device(self._device):
             torch.cuda.synchronize()
+            # the masked stream of an earlier call is ours (artalk_op_create_masked_stream): nothing is queued on it after the
+            # synchronize above, and the ExternalStream wrapper does not own the handle, so it is destroyed here
+            old = getattr(self, "_masked_handle", None)
+            if old is not None:
+                self._stream = None
+                L.artalk_op_destroy_stream(C.c_void_p(old))
+                self._masked_handle = None
             if words is None:
                 if L.artalk_set_cu_mask(self._h, None, 0) != capi.OK:
                     raise RuntimeError("artalk_set_cu_mask failed: " + self._err())
@@ -239,6 +247,7 @@ class BitwiseARModel:
             out = C.c_void_p()
             if L.artalk_op_create_masked_stream(C.cast(arr, C.c_void_p), len(words), C.byref(out)) != capi.OK:
                 raise RuntimeError("hipExtStreamCreateWithCUMask failed")
+            self._masked_handle = out.value
             self._stream = torch.cuda.ExternalStream(out.value, device=self._device)
 
     def get_profile(self):
@@ -412,7 +421,7 @@ class BitwiseARModel:
 
     @torch.no_grad()
     def inference_batch(self, audios: Sequence[torch.Tensor], style_motions: Optional[Sequence[Optional[torch.Tensor]]] = None,
-                        return_aux: bool = False, check: bool = True) -> List[torch.Tensor]:
+                        return_aux: bool = False, check: bool = True, taps: bool = False) -> List[torch.Tensor]:
         """B independent clips -> list of ``(ceil(N_b/640), 106)`` float32 tensors on ``self.device``.
 
         ``check=False`` returns without waiting for the call's health flags (the one host synchronisation of a call), so that a
@@ -421,7 +430,9 @@ class BitwiseARModel:
         in f16x3 mode: redo that batch with ``set_precision("f32")``).
 
         With ``return_aux`` the per-chunk bits, history bits and wav2vec2 features of the call are kept in
-        ``self.last_aux`` (used by the parity tests).
+        ``self.last_aux`` (used by the parity tests).  ``taps`` (with ``return_aux``) additionally records the intermediates of
+        ``artalk_set_tap`` (block inputs / outputs, logits, decoder output, history tokens; the body then runs eagerly, without
+        graphs) as ``last_aux["taps"][clip][field]`` = ``(n_chunks, rows, cols)`` tensors.
         """
         if not self._loaded:
             raise RuntimeError("load_state_dict must be called before inference")
@@ -478,15 +489,25 @@ class BitwiseARModel:
                     bits = torch.zeros(B, maxch, 181, 32, dtype=torch.uint8, device=dev)
                     hist = torch.zeros(B, maxch + 1, 181, 32, dtype=torch.uint8, device=dev)
                     w2v = torch.zeros(total, 199, self.cfg.cond_dim, dtype=torch.float32, device=dev)
+            tap_t = None
+            if taps and return_aux:
+                lay = (C.c_int64 * 7)()
+                L.artalk_tap_layout(lay, 7)
+                with torch.cuda.stream(self._stream):
+                    tap_t = torch.zeros(maxch * B, int(lay[6]), dtype=torch.float32, device=dev)
+                if L.artalk_set_tap(self._h, capi.ptr(tap_t), B, maxch) != capi.OK:
+                    raise RuntimeError("artalk_set_tap failed: " + self._err())
             nch_sorted = (C.c_int64 * B)(*[nch[i] for i in order])
             rc = L.artalk_infer(self._h, capi.ptr(audio_pad), audio_pad.stride(0), nch_sorted, B, capi.ptr(style_t),
                                 C.cast(has, C.c_void_p) if has is not None else None, capi.ptr(out), out.stride(0),
                                 capi.ptr(bits), capi.ptr(hist), capi.ptr(w2v), C.c_void_p(self._stream.cuda_stream))
             caller.wait_stream(self._stream)
+            if tap_t is not None:
+                L.artalk_set_tap(self._h, None, 0, 0)        # (synchronises: the tap buffer is complete)
             for t in (audio_pad, style_t):
                 if t is not None:
                     t.record_stream(self._stream)
-            for t in (out, bits, hist, w2v):           # allocated on the call's stream, read by the caller's from here on
+            for t in (out, bits, hist, w2v, tap_t):           # allocated on the call's stream, read by the caller's from here on
                 if t is not None:
                     t.record_stream(caller)
             if rc != capi.OK:
@@ -495,7 +516,7 @@ class BitwiseARModel:
                 # an activation left fp16's range: redo this call with exact fp32 MFMA GEMMs (never silently return NaNs) and
                 # stay in f32 mode - a checkpoint that trips once trips again, and both runs per call would cost 3.4x
                 self._trip_to_f32("inference_batch")
-                return self.inference_batch(audios, style_motions, return_aux)
+                return self.inference_batch(audios, style_motions, return_aux, taps=taps)
             results: List[Optional[torch.Tensor]] = [None] * B
             for pos, i in enumerate(order):
                 results[i] = out[pos, :seq[i]]                               # truncate, app/models.py:115
@@ -513,4 +534,13 @@ class BitwiseARModel:
                     "hist_bits": [hist[pos, :nch[i] + 1] for pos, i in sorted(enumerate(order), key=lambda t: t[1])],
                     "w2v": w2v, "w2v_index": w2v_idx, "order": order, "n_chunks": nch,
                 }
+                if tap_t is not None:
+                    names = ["blk0_in", "blk0_out", "blkL_out", "prev_in", "logits", "dec_out"]
+                    shapes = [(181, self.cfg.embed_dim)] * 4 + [(181, 2 * self.cfg.code_dim), (200, self.cfg.motion_dim)]
+                    slots = tap_t.view(maxch, B, -1)
+                    per_clip = [None] * B
+                    for pos, i in enumerate(order):
+                        per_clip[i] = {nm: slots[:nch[i], pos, int(lay[k]):int(lay[k]) + r * c_].reshape(nch[i], r, c_)
+                                       for k, (nm, (r, c_)) in enumerate(zip(names, shapes))}
+                    self.last_aux["taps"] = per_clip
         return results

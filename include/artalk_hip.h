@@ -142,9 +142,9 @@ int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, v
  * LAST artalk_infer's numbers (milliseconds / counters):
  *   out[0] style  out[1] wav2vec2 conv stack  out[2] wav2vec2 encoder  out[3] AdaLN table GEMM
  *   out[4] AR scale steps (level 1: whole captured body)  out[5] VAE decode+re-encode (level 2 only; + initial history)
- *   out[6] total  out[7] bracketed launches of the dominant kernel (f16x3 mode: gemm_p8_256_kernel, the 256x256-tile LDS-DMA split GEMM of
- *   the wav2vec2 q|k|v / FFN-in layers, conv1-3 and the AdaLN table; f32 mode: the 128x128-tile fp32 MFMA GEMM)  out[8] their summed ms
- *   out[9] their summed FLOP */
+ *   out[6] total  out[7] bracketed launches of the dominant kernel (f16x3 mode: gemm_p8_big_kernel, the persistent 320x256 / 256x256-tile
+ *   LDS-DMA split GEMM that takes every large GEMM of a step: wav2vec2 q|k|v, out-projection, FFN-in, FFN-out, the feature projection,
+ *   conv1-6 and the AdaLN tables; f32 mode: the 128x128-tile fp32 MFMA GEMM)  out[8] their summed ms  out[9] their summed FLOP */
 int artalk_set_profiling(artalk_model* m, int level);
 int artalk_get_profile(artalk_model* m, double* out, int n);
 /* GEMM arithmetic: 0 (default) = exact fp32 on v_mfma_f32_32x32x2_f32; 1 = "f16x3": every fp32 operand split into two
@@ -162,11 +162,28 @@ int artalk_set_graphs(artalk_model* m, int enable);
  * names NUL-separated, values[i] the maximum seen at site i since the audit was switched on (tools/p8_headroom.py). */
 int artalk_set_audit(artalk_model* m, int enable);
 int artalk_get_audit(artalk_model* m, char* names_buf, int buf_len, float* values, int max_n);
+/* Intermediate taps: device buffers that correspond to intermediates of the reference, for parity tests that localise a difference to
+ * a kernel group (tests/test_taps_gpu.py against tests/golden/taps_*.npz, captured from the reference by oracle/make_golden_taps.py).
+ * While a tap buffer is set, artalk_infer runs the AR/VAE body eagerly as one clip group and copies, for chunk index j and clip
+ * position b (clips in the call's sorted order), into slot (j * max_batch + b), as fp32 (artalk_tap_layout gives the field offsets):
+ *   blk0_in  [181][768]  attn_feat entering attn_blocks[0], rows of scale step p written at step p        (app/models.py:100)
+ *   blk0_out [181][768]  output of attn_blocks[0]                                                          (app/transformer.py:30-43)
+ *   blkL_out [181][768]  output of the last block                                                          (app/models.py:101-102)
+ *   prev_in  [181][768]  prev_attn_feat + prev_lvl_pos_embed as chunk j uses it                            (app/models.py:101,111-114)
+ *   logits   [181][64]   pred_motion_logits, fp32                                                          (app/models.py:103)
+ *   dec_out  [200][106]  VAE decoder output before unnorm_with_stats                                       (app/modules/bitwise_vae.py:110-111)
+ * With the KV cache only a scale step's NEW tokens are computed, so row t holds the value of the step that introduced token t -
+ * which the reference recomputes, bit-identically, in every later step.  tap_dev = NULL switches the taps off. */
+int artalk_set_tap(artalk_model* m, float* tap_dev, int max_batch, int max_chunks);
+int artalk_tap_layout(int64_t* out, int n);
 /* Restrict the model to a set of compute units: bit i of mask[0 .. n_words) = CU i / 8 of XCD i % 8 on MI355X.  The library's own
  * streams get the mask and its persistent kernels size their grids to it; the caller passes a stream created with the same mask
  * (artalk_op_create_masked_stream) to artalk_infer - e.g. to leave compute units to a renderer running beside the path.  (Two
  * replicas of the path on the two halves of the chip measured 18 % BELOW one replica on the whole chip: tools/dual_partition_probe.py,
- * DESIGN.md section 6.)  n_words = 0 clears it. */
+ * DESIGN.md section 6.)  n_words = 0 clears it.  A stream created with a CU mask (hipExtStreamCreateWithCUMask) is a BLOCKING stream:
+ * unlike the library's unmasked side streams (hipStreamNonBlocking) it is implicitly ordered against work on the legacy null stream
+ * of the process, and a null-stream call made while the library captures a graph on it is a capture error - keep other GPU work of
+ * the process (a renderer) on streams of its own while a partitioned model runs.  The mask count is clamped to the device's CUs. */
 int artalk_set_cu_mask(artalk_model* m, const uint32_t* mask, int n_words);
 
 /* ---- single-kernel entry points for the parity tests (device pointers, row-major f32) ---- */
@@ -185,6 +202,9 @@ int artalk_op_gemm_f16s(const float* A, int64_t lda, const float* W, const float
 int artalk_op_pack_split(const float* in, void* out_u32, int64_t n, int is_weight, void* stream);   /* operand scale: 0 activation, 1 weight */
 int artalk_op_gemm_f16s_packed(const void* A, int a_packed, int64_t lda, const void* Wp, const float* bias, float* C, int M, int N,
                                int K, int act, int force_cfg, void* stream);
+/* frees the split-K scratch artalk_op_gemm_f16s_packed grows on demand (the buffers it outgrew are kept until this call, because
+ * graphs captured from earlier launches still write to them): call it when no such graph will be replayed again */
+int artalk_op_release_scratch(void);
 /* which production LDS-DMA kernel launch_gemm_p8 picks for an M x N x K product (dense rows, with or without a residual) with both
  * operands in P8 and no forced configuration (what the model path calls): 7 / 12 = gemm_p8_big_kernel with 256x256 / 320x256 tiles,
  * 8 = gemm_p8_2wgp_kernel; force_cfg 99 of artalk_op_gemm_f16s_packed launches exactly that choice */

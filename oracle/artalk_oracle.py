@@ -239,6 +239,7 @@ class ARTalkOracle:
         w, T = self.w, self.cfg.frames_per_chunk
         vq = torch.cat([self.vqidx_to_feat(prev_bits, False), self.vqidx_to_feat(this_bits, False)], dim=1)
         dec = self.vae_stack("decoder", vq + w["basic_vae.dec_pos_embed"], w["basic_vae.attn_mask"])
+        self._last_dec_out = dec                                                            # (tap: decoder output before unnorm)
         motion = dec * w["basic_vae.motion_std"] + w["basic_vae.motion_mean"]              # :63-65
         return motion[:, :T], motion[:, T:]
 
@@ -299,20 +300,38 @@ class ARTalkOracle:
         if record is not None:
             record.update(bits=[], hist_bits=[prev_bits.clone()], logit_margin=[], hist_margin=[hist_margin.clone()],
                           w2v=[], style_cond=style_cond.clone())
+        # intermediates in the layout of the device taps (include/artalk_hip.h: artalk_set_tap; reference-captured goldens:
+        # oracle/make_golden_taps.py): row t of the block / logit tensors comes from the scale step that introduces token t
+        taps = record.get("taps") if record is not None else None
+        if taps is not None:
+            taps.update(blk0_in=[], blk0_out=[], blkL_out=[], prev_in=[], logits=[], dec_out=[])
         out = []
         for chunk in chunks:
             feat_a = self.wav2vec(chunk).permute(0, 2, 1)
             conds = [F.interpolate(feat_a, size=(p), mode="area").permute(0, 2, 1) for p in pn]    # :94
             cond_all = torch.cat(conds, dim=1)
             nxt = style_cond
+            if taps is not None:
+                taps["prev_in"].append((prev_attn_feat + prev_lvl_pos)[0].clone())
+                for k in ("blk0_in", "blk0_out", "blkL_out"):
+                    taps[k].append(torch.zeros(NT, lvl_pos.shape[-1]))
+                taps["logits"].append(torch.zeros(NT, 2 * cfg.code_dim))
             for pidx in range(len(pn)):
                 L = sum(pn[:pidx + 1])
+                new = slice(L - pn[pidx], L)
                 cond = cond_all[:, :L]
                 bias = w["attn_bias_for_masking"][:, :, :L, :L + NT * cfg.prev_ratio]
                 x = nxt + lvl_pos[:, :nxt.shape[1]]
                 for i in range(cfg.ar_depth):
+                    if taps is not None and i == 0:
+                        taps["blk0_in"][-1][new] = x[0, new]
                     x = self.ar_block(i, x, prev_attn_feat + prev_lvl_pos, cond, bias)
+                    if taps is not None and i == 0:
+                        taps["blk0_out"][-1][new] = x[0, new]
                 logits = self.ar_head(x, cond)
+                if taps is not None:
+                    taps["blkL_out"][-1][new] = x[0, new]
+                    taps["logits"][-1][new] = logits[0, new]
                 pairs = logits.view(B, L, -1, 2)
                 bits = pairs.argmax(dim=-1)                                                          # :104
                 for (tok, bit) in force_bits.get(len(out), ()):          # (test infrastructure only, see the docstring)
@@ -322,6 +341,8 @@ class ARTalkOracle:
                     nxt = self.vqidx_to_ar_vqfeat(pidx, bits)
                     nxt = torch.cat([style_cond, F.linear(nxt, w["vqfeat_embed.weight"], w["vqfeat_embed.bias"])], dim=1)
             _, pred = self.vqidx_to_motion(prev_bits, bits)
+            if taps is not None:
+                taps["dec_out"].append(self._last_dec_out[0].clone())
             out.append(pred)
             new_prev_bits, hm = self.quant_to_vqidx(pred, force_hist.get(len(out), ()))
             if record is not None:

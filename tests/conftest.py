@@ -81,7 +81,41 @@ def golden_inputs(g, sd):
 TAU_LOGIT = 2e-5     # |l0 - l1| of the reference at a flipped AR bit (the reference's own fixtures reach down to 1.1e-5)
 TAU_HIST = 2e-6      # |z| (unit-normalised) of the reference at a flipped history bit
 FLAME_TOL = 1e-3
+# Regression guard beside the bar: every run of rounds 1-3 measured 3e-7 .. 8.3e-7 on the FLAME codes of decision-exact chunks, so a
+# kernel that loses a decimal digit fails HERE, before it starts to re-roll which clips flip.
+FLAME_GUARD = 5e-6
 ALLOWED_MARGINAL = {}    # {(case, precision): first chunk allowed to differ}
+
+# The PINNED set of rounding-level clips: {"<clip tag>|<precision>": stages}.  A clip that is not listed must equal the
+# reference golden outright; a listed clip may follow at most the listed number of chained rounding-level flips.  A change of
+# arithmetic that re-rolls the set therefore FAILS until the file is edited deliberately (ARTALK_ROUNDING_DISCOVER=1 records what
+# a run observes in gpurun_out/rounding_level_observed.json without failing on the pin; the margin / continuation bar still holds).
+ROUNDING_PIN_FILE = os.path.join(GOLDEN, "rounding_level_expected.json")
+ROUNDING_OBSERVED = {}      # filled by assert_clip_parity, written at session end
+
+
+def rounding_pin():
+    import json
+    if "pin" not in _cache:
+        _cache["pin"] = json.load(open(ROUNDING_PIN_FILE))["clips"] if os.path.exists(ROUNDING_PIN_FILE) else {}
+    return _cache["pin"]
+
+
+def clip_key(tag, precision):
+    """'cfg4 clip 5 (jp2, style 205)' -> 'cfg4 clip 5|f16x3': the clip and the batch it runs in (tile shapes, hence the fp32 summation
+    order, depend on the batch), not the free-text suffix."""
+    return tag.split(" (")[0] + "|" + precision
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not ROUNDING_OBSERVED:
+        return
+    import json
+    d = os.path.join(REPO, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "rounding_level_observed.json"), "w") as f:
+        json.dump({"clips": {k: v for k, v in sorted(ROUNDING_OBSERVED.items()) if v["stages"]},
+                   "checked": len(ROUNDING_OBSERVED)}, f, indent=1)
 
 
 _LEVEL_OF = None
@@ -182,6 +216,15 @@ def assert_clip_parity(tag, precision, out, bits, hist, gout, gbits, ghist, logi
     if stages:
         print("NOTE " + msg)
     assert err < FLAME_TOL, msg
+    assert err < FLAME_GUARD, "precision regression (bar 1e-3 still met, guard = measured 8e-7 + margin): " + msg
+    key = clip_key(tag, precision)
+    ROUNDING_OBSERVED[key] = dict(stages=stages, note=note.strip())
+    pinned = int(rounding_pin().get(key, 0))
+    if stages < pinned:
+        print(f"NOTE {key}: pinned at {pinned} rounding-level stage(s), this run followed {stages} - the pin can be tightened")
+    if not os.environ.get("ARTALK_ROUNDING_DISCOVER"):
+        assert stages <= pinned, (f"{key} followed {stages} rounding-level flip(s) but tests/golden/rounding_level_expected.json pins "
+                                  f"{pinned}: a change of arithmetic re-rolled the set - check the cause, then edit the pin deliberately. " + msg)
     if diff is not None and diff["chunk"] < n_chunks:
         allowed = ALLOWED_MARGINAL.get((tag, precision), ALLOWED_MARGINAL.get((tag, "*")))
         assert diff["marginal"] and allowed is not None and diff["chunk"] >= allowed, msg

@@ -134,3 +134,78 @@ def test_config2_batch32_synthetic_10s(precision):
     finally:
         m.set_precision("f32")
     print(f"configs[2] [{precision}]: 8 golden clips decision-exact, worst FLAME max-abs err {worst:.3e}; rounding_level_clips = {len(rounding)} {rounding}")
+
+
+def test_config3_workload_on_one_gpu():
+    """BASELINE configs[3]'s WORKLOAD - 256 synthetic 10 s clips (seeds 0..255) sharded 8 x 32 - pushed through the HIP path on ONE
+    GPU, shard by shard, through the same function the ranks of an 8-GPU job call (artalk_amd.dist.run_sharded, local path of rank
+    r of 8).  No RCCL claim and nothing about scaling: no 8-GPU node was available, and no scaling curve has been measured.
+    Checks: the partition (every seed exactly once, rank-major order = input order), seeds 0..7 against the reference's own
+    outputs (tests/golden/full_cfg2_synth8.npz, odd seeds styled), a sample of later seeds - one per shard - against their
+    batch-1 runs (decisions identical, codes to 1e-5), and determinism (a shard run twice is bit-identical)."""
+    from artalk_amd import dist as adist
+    from artalk_amd.synth import synth_audio, synth_style
+    clips = load_clip_set("full_cfg2_synth8")
+    cfg, sd = get_state_dict("full")
+    mean, std = sd["basic_vae.motion_mean"].numpy(), sd["basic_vae.motion_std"].numpy()
+    N, W = 256, 8
+
+    class Clips:           # lazy: only the shard that is asked for is synthesised (as bench.py's ClipList does)
+        def __len__(self):
+            return N
+
+        def __getitem__(self, i):
+            return torch.from_numpy(synth_audio(i, 10.0))
+
+    class Styles:          # seeds 1, 3, 5, 7 styled as in the golden set; one styled clip in every later shard as well
+        def __len__(self):
+            return N
+
+        def __getitem__(self, i):
+            return torch.from_numpy(synth_style(i, mean, std)) if ((i < 8 and i % 2 == 1) or i % 32 == 9) else None
+
+    m = get_gpu_model("full")
+    m.set_precision("f16x3")
+    seen, results, aux_bits, aux_hist = [], {}, {}, {}
+    try:
+        for r in range(W):
+            mine = adist.shard_range(N, r, W)
+            assert len(mine) == 32
+            calls = []
+
+            def infer_fn(a, s_):
+                calls.append(len(a))
+                return m.inference_batch(a, s_, return_aux=True)
+            outs = adist.run_sharded(infer_fn, Clips(), Styles(), gather=False, as_rank=(r, W))
+            assert calls == [32] and len(outs) == 32
+            assert m._precision == "f16x3" and m.status() == 0
+            for k, i in enumerate(mine):
+                assert outs[k].shape == (250, 106)
+                results[i] = outs[k].cpu().numpy()
+                aux_bits[i] = m.last_aux["bits"][k].cpu().numpy()
+                aux_hist[i] = m.last_aux["hist_bits"][k].cpu().numpy()
+            seen += list(mine)
+            if r in (0, 5):        # determinism: the same shard again, bit for bit
+                again = adist.run_sharded(lambda a, s_: m.inference_batch(a, s_), Clips(), Styles(), gather=False, as_rank=(r, W))
+                assert all(np.array_equal(again[k].cpu().numpy(), results[i]) for k, i in enumerate(mine))
+        assert seen == list(range(N)), "rank-major concatenation of the shards must be the input order, every clip exactly once"
+        # seeds 0..7 (all in shard 0) against the reference itself
+        worst, rounding = 0.0, []
+        for i, c in enumerate(clips):
+            a_i, s_i = Clips()[i], Styles()[i]
+            good, n, err = assert_clip_parity(f"cfg3 clip {i}", "f16x3", results[i], aux_bits[i], aux_hist[i], c["out"], c["bits"], c["hist_bits"],
+                                              c["logit_margin"], c["hist_margin"], inputs=("full", a_i, s_i))
+            worst = max(worst, err)
+            if assert_clip_parity.last_rounding_level:
+                rounding.append(i)
+        # one clip of every shard (a styled one among them) against its batch-1 run
+        for i in (21, 41, 77, 100, 137, 190, 201, 255):
+            so, sb, sh = _run_set(m, [Clips()[i]], [Styles()[i]])
+            assert (sb[0] == aux_bits[i]).all() and (sh[0] == aux_hist[i]).all(), f"clip {i}: decisions differ between its shard of 32 and batch 1"
+            assert np.abs(so[0] - results[i]).max() < 1e-5
+        # different seeds really are different clips (the shards did not all compute shard 0)
+        assert not np.array_equal(results[0], results[32]) and not np.array_equal(results[32], results[64])
+    finally:
+        m.set_precision("f32")
+    print(f"configs[3] workload on one GPU: 256 clips in 8 shards of 32, seeds 0..7 decision-exact vs the reference (worst FLAME "
+          f"max-abs err {worst:.3e}, rounding_level_clips = {rounding}), 8 sampled clips equal their batch-1 runs; NO scaling measured")

@@ -44,7 +44,9 @@ def test_against_reference_golden(case, precision):
     # wav2vec2 features (third-party arithmetic pinned by the golden slice)
     w2v = aux["w2v"].cpu().numpy()
     w2v_err = np.abs(w2v[:, :, :16] - g["w2v_slice"]).max()
-    assert w2v_err < 2e-3, f"{case} [{precision}]: wav2vec2 feature slice differs by {w2v_err:.3e}"
+    # guard = measured (4e-6 .. 1e-5 over rounds 1-3, features of magnitude ~1 after the final LayerNorm) + margin: a kernel that loses
+    # a decimal digit fails here before it re-rolls decisions (the bar itself is the decisions + 1e-3 on the codes)
+    assert w2v_err < 5e-5, f"{case} [{precision}]: wav2vec2 feature slice differs by {w2v_err:.3e}"
     assert abs(np.abs(w2v).mean() - float(g["w2v_abs_mean"])) < 1e-4
     good, n_chunks, err = golden_parity(case, precision, out, aux, g, inputs=(name, audio, style))
     print(f"{case} [{precision}]: chunks exact {good}/{n_chunks}, FLAME max-abs err {err:.3e}, w2v err {w2v_err:.3e}")

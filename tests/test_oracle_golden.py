@@ -126,3 +126,32 @@ def test_forced_decision_continuation_fixture():
     mask = np.zeros((181, 32), bool)
     mask[tok, bit] = True
     assert c["hist_margin"](h0, mask)[0] < TAU_HIST
+
+
+TAP_FIELDS = ["blk0_in", "blk0_out", "blkL_out", "prev_in", "logits", "dec_out"]
+
+
+def test_oracle_intermediates_match_reference_taps():
+    """The oracle's INTERMEDIATES against tensors hooked out of the reference itself (oracle/make_golden_taps.py ->
+    tests/golden/taps_tiny_10s_s1_style.npz): block inputs / outputs, fp32 logits, decoder output before unnorm, the history
+    tokens every chunk uses, the style condition.  Also records the premise of the KV cache on the reference's own numbers: the rows
+    of earlier tokens, which the reference recomputes in every later scale step, move only by its BLAS's row-count-dependent
+    blocking (recompute_max_abs ~ 1e-6; the bit-level statement is test_kv_cache_is_legal)."""
+    case = "tiny_10s_s1_style"
+    t = load_golden("taps_" + case)
+    assert float(t["recompute_max_abs"]) < 1e-5
+    g = load_golden(case)
+    o = get_oracle("tiny")
+    cfg, sd = get_state_dict("tiny")
+    audio, style = golden_inputs(g, sd)
+    rec = {"taps": {}}
+    o.inference({"audio": audio[None], "style_motion": style[None]}, record=rec)
+    cs = int(t["col_stride"])
+    for f in TAP_FIELDS:
+        mine = torch.stack(rec["taps"][f]).numpy()[:t[f].shape[0]]
+        if mine.shape[-1] == 768:
+            mine = mine[:, :, ::cs]
+        assert mine.shape == t[f].shape, f
+        err = np.abs(mine - t[f]).max()
+        assert err < 1e-5, f"{f}: oracle differs from the reference's intermediate by {err:.3e}"
+    assert np.abs(rec["style_cond"].reshape(-1).numpy() - t["style_cond"]).max() < 1e-6

@@ -1,0 +1,78 @@
+"""Reference-captured INTERMEDIATES against the device buffers of the HIP path (VERDICT r3 missing #2).
+
+tests/golden/taps_*.npz hold tensors hooked out of the reference itself (oracle/make_golden_taps.py): the input and output of
+``attn_blocks[0]``, the output of the last block, the fp32 logits, the VAE decoder output before ``unnorm_with_stats``, the
+history tokens ``prev_attn_feat + prev_lvl_pos_embed`` every chunk uses, and the style condition.  The device exposes the
+matching buffers through ``artalk_set_tap`` (include/artalk_hip.h).  End-to-end parity says WHETHER a decision differs; these
+say WHERE: the report lists the error of every kernel group in causal order, so a flip can be attributed from the test output
+alone (style encoder -> history re-encode / BSQ / vq-embed -> block 0 -> block stack -> head -> VAE decoder).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import get_gpu_model, get_state_dict, golden_inputs, load_golden
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ["prev_in", "blk0_in", "blk0_out", "blkL_out", "logits", "dec_out"]      # causal order inside a chunk
+# relative to the field's own scale (max |reference|).  Measured (round 4): 1e-7 .. 3e-6; the bar asked for is 1e-5.
+TOL_REL = 1e-5
+OFF = (0, 1, 6, 31, 81, 181)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("case", ["tiny_10s_s1_style", "full_5p5s_s3_style"])
+def test_intermediates_against_reference(case, precision):
+    t = load_golden("taps_" + case)
+    g = load_golden(case)
+    name = case.split("_")[0]
+    m = get_gpu_model(name)
+    cfg, sd = get_state_dict(name)
+    audio, style = golden_inputs(g, sd)
+    m.set_precision(precision)
+    try:
+        out = m.inference_batch([audio], [style], return_aux=True, taps=True)[0].cpu().numpy()
+        assert m._precision == precision and m.status() == 0
+        taps = {k: v.cpu().numpy() for k, v in m.last_aux["taps"][0].items()}
+        bits = m.last_aux["bits"][0].cpu().numpy()
+        # the tapped (eager, one clip group) run and the production (hipGraph) run of the same clip agree
+        plain = m.inference_batch([audio], [style], return_aux=True)[0].cpu().numpy()
+        assert np.array_equal(m.last_aux["bits"][0].cpu().numpy(), bits) and np.abs(plain - out).max() < 1e-5
+        # style condition (app/models.py:67-73) through the style-cache entry point
+        st = style.cuda()[None]
+        cond = torch.empty(1, 768, device="cuda")
+        import ctypes as C
+        from artalk_amd import capi
+        s = torch.cuda.current_stream()
+        assert capi.lib().artalk_style_encode(m._h, capi.ptr(st), 1, capi.ptr(cond), C.c_void_p(s.cuda_stream)) == 0
+        torch.cuda.synchronize()
+    finally:
+        m.set_precision("f32")
+    n_chunks, cs = t["blk0_in"].shape[0], int(t["col_stride"])      # the fixture keeps the first chunks and every cs-th column of the 768-wide fields
+    taps = {k: (v[:, :, ::cs] if v.shape[-1] == 768 else v) for k, v in taps.items()}
+    gbits = np.unpackbits(g["bits"], axis=-1)
+    report, worst = [], 0.0
+    sc_err = float(np.abs(cond[0].cpu().numpy() - t["style_cond"]).max() / np.abs(t["style_cond"]).max())
+    report.append(f"style_cond {sc_err:.1e}")
+    worst = max(worst, sc_err)
+    exact = True
+    for c in range(n_chunks):
+        for f in FIELDS:
+            ref, mine = t[f][c], taps[f][c]
+            if f in ("blk0_in", "blk0_out", "blkL_out", "logits"):      # per scale step: which step first moves away
+                errs = [float(np.abs(mine[OFF[p]:OFF[p + 1]] - ref[OFF[p]:OFF[p + 1]]).max() / np.abs(ref).max()) for p in range(5)]
+                report.append(f"chunk {c} {f} per step " + " ".join(f"{e:.1e}" for e in errs))
+                e = max(errs)
+            else:
+                e = float(np.abs(mine - ref).max() / np.abs(ref).max())
+                report.append(f"chunk {c} {f} {e:.1e}")
+            if exact:            # intermediates are comparable only while every earlier decision of the clip is the reference's
+                worst = max(worst, e)
+        exact = exact and bool((bits[c] == gbits[c]).all())
+        if not exact:
+            report.append(f"chunk {c}: decisions differ from the reference (a rounding-level flip is judged by test_e2e_gpu); later chunks are not compared")
+            break
+    text = f"{case} [{precision}] intermediates vs the reference (relative to each field's scale):\n  " + "\n  ".join(report)
+    print(text)
+    assert worst < TOL_REL, text

@@ -59,7 +59,9 @@ for name, M, N, K in SHAPES:
         a = Ap if apk else A
         L.artalk_op_gemm_f16s_packed(p(a), apk, K, p(Wp), p(b), p(Cc), M, N, K, ACT, cfg, s)      # warm-up (allocates the split-K scratch)
         torch.cuda.synchronize()
-        err = float((Cc[:256].double() - ref).abs().max() / ref.abs().max())
+        # the error column is a CHECK only for an fp32 result without an in-place residual: a P8 result (ACT & 0x100) read as fp32, or a
+        # residual accumulated over the repeats (ACT & 0x200), is timing only and printed as n/a
+        err = None if (ACT & 0x300) else float((Cc[:256].double() - ref).abs().max() / ref.abs().max())
         graph = None
         if os.environ.get("GEMM_GRAPH", "1") == "1" and M * N * K < 1e11:
             # the launches replayed from a hipGraph, as the model runs them: eager launches are host-bound below ~3.5 us per kernel
@@ -83,5 +85,8 @@ for name, M, N, K in SHAPES:
     for v in runs:
         best = sorted(v["ts"])[len(v["ts"]) // 2]
         cfg = v["cfg"]
-        line += f"| cfg{cfg & 0xff}{'/%d' % (cfg >> 8) if cfg >> 8 else ''}{'P' if v['apk'] else ' '}: {best*1e3:8.1f} us {2*M*N*K/best/1e9:6.1f} TF e={v['err']:.0e} "
+        line += f"| cfg{cfg & 0xff}{'/%d' % (cfg >> 8) if cfg >> 8 else ''}{'P' if v['apk'] else ' '}: {best*1e3:8.1f} us {2*M*N*K/best/1e9:6.1f} TF e={'n/a  ' if v['err'] is None else '%.0e' % v['err']} "
     print(line, flush=True)
+    del runs      # the graphs that replay launches into the split-K scratch are gone: retired scratch buffers may be freed
+    torch.cuda.synchronize()
+    L.artalk_op_release_scratch()
