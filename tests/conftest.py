@@ -18,34 +18,45 @@ def pytest_configure(config):
 _cache = {}
 
 
-def get_state_dict(name):
-    """Deterministic synthetic weights of config `name` ('tiny' | 'full'), generated once per session."""
-    if name not in _cache:
+def get_state_dict(name, profile="benign"):
+    """Deterministic synthetic weights of config `name` ('tiny' | 'full'), generated once per session.  `profile`: the benign
+    U(+-1/sqrt(fan_in)) weights of every round, or one of the outlier profiles of artalk_amd.weights.PROFILES."""
+    key = name if profile == "benign" else (name, profile)
+    if key not in _cache:
         from artalk_amd.config import ARTalkConfig
         from artalk_amd.weights import generate_state_dict
         cfg = ARTalkConfig.by_name(name)
-        _cache[name] = (cfg, generate_state_dict(cfg))
-    return _cache[name]
+        _cache[key] = (cfg, generate_state_dict(cfg, profile=profile))
+    return _cache[key]
 
 
 _models = {}
 
 
-def get_gpu_model(name):
-    """HIP model with the synthetic weights loaded (one per config per session)."""
-    if name not in _models:
+def get_gpu_model(name, profile="benign"):
+    """HIP model with the synthetic weights loaded (one per config and weight profile per session)."""
+    key = name if profile == "benign" else (name, profile)
+    if key not in _models:
         from artalk_amd.model import BitwiseARModel
-        cfg, sd = get_state_dict(name)
+        cfg, sd = get_state_dict(name, profile)
         m = BitwiseARModel(cfg).eval().to("cuda")
         m.load_state_dict(sd, strict=True)
-        _models[name] = m
-    return _models[name]
+        _models[key] = m
+    return _models[key]
 
 
-def get_oracle(name):
+def drop_profile(name, profile):
+    """Free the host and device copies of a non-default weight profile (2 GB + 4 GB each at the full size)."""
+    key = (name, profile)
+    _models.pop(key, None)
+    _cache.pop(key, None)
+    _cache.pop(("oracle",) + key, None)
+
+
+def get_oracle(name, profile="benign"):
     from artalk_oracle import ARTalkOracle
-    cfg, sd = get_state_dict(name)
-    key = ("oracle", name)
+    cfg, sd = get_state_dict(name, profile)
+    key = ("oracle", name) if profile == "benign" else ("oracle", name, profile)
     if key not in _cache:
         _cache[key] = ARTalkOracle(cfg, sd)
     return _cache[key]
@@ -164,7 +175,7 @@ def oracle_continuation(config_name, audio, style, force_hist, force_bits):
     import numpy as np
     import torch
     rec = {}
-    o = get_oracle(config_name)
+    o = get_oracle(*config_name) if isinstance(config_name, tuple) else get_oracle(config_name)      # (name, weight profile) or name
     out = o.inference({"audio": audio[None], "style_motion": style[None] if style is not None else None}, record=rec,
                       force_hist=force_hist, force_bits=force_bits)[0].numpy()
     return dict(out=out, bits=torch.cat(rec["bits"]).numpy().astype(np.uint8), hist_bits=torch.cat(rec["hist_bits"]).numpy().astype(np.uint8),

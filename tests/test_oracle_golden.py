@@ -155,3 +155,20 @@ def test_oracle_intermediates_match_reference_taps():
         err = np.abs(mine - t[f]).max()
         assert err < 1e-5, f"{f}: oracle differs from the reference's intermediate by {err:.3e}"
     assert np.abs(rec["style_cond"].reshape(-1).numpy() - t["style_cond"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("case", ["outlier_tiny_10s_s1_style", "heavy_tiny_6p3s_s2"])
+def test_oracle_matches_reference_outlier_profiles(case):
+    """The oracle on the outlier weight profiles (artalk_amd.weights.PROFILES) against the reference's own outputs on the same
+    weights (oracle/make_golden_profiles.py): pins the checker that judges rounding-level continuations for those profiles."""
+    g = load_golden(case)
+    profile, name = case.split("_")[0], case.split("_")[1]
+    o = get_oracle(name, profile)
+    cfg, sd = get_state_dict(name, profile)
+    audio, style = golden_inputs(g, sd)
+    rec = {}
+    out = o.inference({"audio": audio[None], "style_motion": style[None] if style is not None else None}, record=rec)[0].numpy()
+    bits = np.packbits(torch.cat(rec["bits"]).numpy().astype(np.uint8), axis=-1)
+    hist = np.packbits(torch.cat(rec["hist_bits"]).numpy().astype(np.uint8), axis=-1)
+    assert (bits == g["bits"]).all() and (hist == g["hist_bits"]).all()
+    assert np.abs(out - g["out"]).max() < 1e-5

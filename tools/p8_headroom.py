@@ -34,14 +34,24 @@ def read_audit(m):
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "profiles", "r02_p8_headroom.json")
-    cfg, sd = get_state_dict("full")
-    m = get_gpu_model("full")
+    # usage: p8_headroom.py [out.json] [--profile outlier|heavy]   (a weight profile of artalk_amd.weights.PROFILES: its own goldens'
+    # inputs plus the demo / synthetic clip sets, on the FULL model)
+    args = [a for a in sys.argv[1:]]
+    profile = "benign"
+    if "--profile" in args:
+        i = args.index("--profile")
+        profile = args[i + 1]
+        del args[i:i + 2]
+    out = args[0] if args else os.path.join(REPO, "profiles", "r02_p8_headroom.json")
+    cfg, sd = get_state_dict("full", profile)
+    m = get_gpu_model("full", profile)
     m.set_precision("f16x3")
+    m.check_finite = False          # the audit records what the format is asked to hold; no f32 re-run here
     L = capi.lib()
     assert L.artalk_set_audit(m._h, 1) == 0
     n_clips = 0
-    for case in CASES:
+    cases = CASES if profile == "benign" else [f"{profile}_full_4s_s2"] + ([f"{profile}_full_5p5s_s3_style"] if profile == "outlier" else []) + CASES
+    for case in cases:
         g = load_golden(case)
         audio, style = golden_inputs(g, sd)
         m.inference_batch([audio], [style])
@@ -58,7 +68,7 @@ def main():
     worst = rows[0]
     res = {
         "what": "max |x| * 16 per producer site of a P8 (f16x3) operand over all golden inputs; limit 65504 (fp16 max)",
-        "weights": "deterministic synthetic weights (seed 1234), reference motion statistics", "clips": n_clips,
+        "weights": f"deterministic synthetic weights (seed 1234, profile '{profile}': artalk_amd.weights.PROFILES), reference motion statistics", "clips": n_clips,
         "status_word": status, "limit": 65504.0,
         "worst_site": worst[0], "worst_value": worst[1], "min_headroom_factor": 65504.0 / max(worst[1], 1e-30),
         "sites": {k: {"max_abs_x16": v, "headroom_factor": (65504.0 / v if v > 0 else None)} for k, v in rows},
