@@ -271,6 +271,18 @@ __global__ __launch_bounds__(256) void enc_input_zero_kernel(const float* __rest
         E[((long)b * T100 + t) * EK + j] = (j < MD) ? ((0.f - mean[j]) / stdv[j] + epos[t * MD + j]) : 0.f;
     }
 }
+// dst[b][0 .. bytes) = src[0 .. bytes) for b < B (bytes % 16 == 0): the initial history of a clip is the same for every clip
+__global__ __launch_bounds__(256) void broadcast16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+    uint4* d = dst + (long)blockIdx.y * n16;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) d[i] = src[i];
+}
+void launch_broadcast16(const void* src, void* dst, long bytes, int B, hipStream_t s) {
+    if (B <= 0 || bytes <= 0) return;
+    const int n16 = (int)(bytes / 16);
+    hipLaunchKernelGGL(broadcast16_kernel, dim3((n16 + 255) / 256 < 8 ? (n16 + 255) / 256 : 8, B), dim3(256), 0, s,
+                       reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16);
+}
+
 void launch_enc_input_zero(const float* mean, const float* stdv, const float* epos, float* E, int B, hipStream_t s) {
     hipLaunchKernelGGL(enc_input_zero_kernel, dim3(B), dim3(256), 0, s, mean, stdv, epos, E, 106, 128);
 }

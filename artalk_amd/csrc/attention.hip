@@ -371,6 +371,9 @@ __global__ __launch_bounds__(256, 2) void attention_short_kernel(const AttnArgs 
 // The V^T operand needs 8 consecutive KEYS per lane at one d: read by ds_read_b64_tr_b16 (4 keys x 16 d block per 16 lanes,
 // delivered column-major), two reads per operand.  The k slots of the PV MFMA are assigned so that the S^T accumulator is the
 // P^T operand without any data movement: slot (g, e) = key 32T + 4g + e for e < 4 (tile 2T), key 32T + 16 + 4g + (e - 4) (tile 2T+1).
+#ifndef ATT_ABL
+#define ATT_ABL 0
+#endif
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
 __device__ __forceinline__ void split4(const f32x4 x, f16x4_t& hi, f16x4_t& lo) {
@@ -637,12 +640,14 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
             const int row = idx >> 3, g8 = idx & 7;
             const h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
             kh[i] = z; kl[i] = z; vh[i] = z; vl[i] = z;
+#if ATT_ABL != 1      // (timing builds, results wrong: ATT_ABL 1 no K / V loads, 2 no softmax arithmetic, 3 one MFMA product of three, 4 no P split)
             if (row < a.Lk) {
                 const unsigned char* kp = reinterpret_cast<const unsigned char*>(Kb + (long)row * a.ldk) + g8 * 32;
                 const unsigned char* vp = reinterpret_cast<const unsigned char*>(Vb + (long)row * a.ldv) + g8 * 32;
                 kh[i] = *reinterpret_cast<const h8_t*>(kp); kl[i] = *reinterpret_cast<const h8_t*>(kp + 16);
                 vh[i] = *reinterpret_cast<const h8_t*>(vp); vl[i] = *reinterpret_cast<const h8_t*>(vp + 16);
             }
+#endif
         }
         // Q fragments (B operand of S^T): lane (r, g) holds Q[qi][8g + 32kb .. +7], hi | lo as stored
         h8_t qh_[2], ql_[2];
@@ -695,8 +700,12 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
                         const int off = (kb0 + t * 16 + r) * PB + (8 * g + 32 * kb) * 2;
                         const h8_t kh2 = *reinterpret_cast<const h8_t*>(Kh + off), kl2 = *reinterpret_cast<const h8_t*>(Kl + off);
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh2, qh[kb], acc, 0, 0, 0);
+#if ATT_ABL != 3
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl2, qh[kb], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh2, ql[kb], acc, 0, 0, 0);
+#else
+                        acc[0] += (float)kl2[0] * (float)ql[kb][0];
+#endif
                     }
                 }
                 st[t] = acc;
@@ -724,6 +733,9 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
                         mx = fmaxf(mx, sv);
                     }
             }
+#if ATT_ABL == 2
+            l_part += mx;
+#else
             mx = fmaxf(mx, lane_xor<16>(mx));
             mx = fmaxf(mx, lane_xor<32>(mx));
             const float m_new = fmaxf(m_run, mx);
@@ -742,12 +754,17 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
             l_part = l_part * alpha + ps;
 #pragma unroll
             for (int d = 0; d < 4; ++d) ot[d] *= alpha;
+#endif
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
                 if (2 * T < ntile) {
                     f16x4_t h0, l0, h1, l1;
+#if ATT_ABL == 4
+                    for (int e = 0; e < 4; ++e) { h0[e] = (_Float16)st[2 * T][e]; h1[e] = (_Float16)st[2 * T + 1][e]; l0[e] = h0[e]; l1[e] = h1[e]; }
+#else
                     split4(st[2 * T], h0, l0);
                     split4(st[2 * T + 1], h1, l1);
+#endif
                     const h8_t ph = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                     const h8_t pl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
                     const int row1 = kb0 + T * 32 + 4 * g + trq, row2 = row1 + 16;
@@ -765,8 +782,12 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
                         const h8_t vh2 = {a1[0], a1[1], a1[2], a1[3], a2[0], a2[1], a2[2], a2[3]};
                         const h8_t vl2 = {b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3]};
                         ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh2, ph, ot[dt], 0, 0, 0);
+#if ATT_ABL != 3
                         ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl2, ph, ot[dt], 0, 0, 0);
                         ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh2, pl, ot[dt], 0, 0, 0);
+#else
+                        ot[dt][0] += (float)vl2[0] * (float)pl[0];
+#endif
                     }
                 }
             }

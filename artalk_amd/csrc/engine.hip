@@ -110,6 +110,11 @@ struct artalk_model {
     unsigned int* audit_vals = nullptr;            // device, kAuditSlots floats (as bits)
     std::vector<std::string> audit_names;
     std::map<std::string, int> audit_index;
+    // The INITIAL history of a clip (app/models.py:86-89: encode + quantise an all-zero motion) is a function of the weights only - the
+    // same bits, decoder features and history tokens for every clip of every call.  It is computed once per precision mode (for ONE
+    // clip, through the same run_reencode as every later history) and broadcast to the batch afterwards; only the style token in
+    // front of the history tokens differs per clip (launch_vq_embed).  [0] exact-f32 mode, [1] f16x3 mode.
+    struct InitHistory { uint8_t* bits = nullptr; float *fdec = nullptr, *msfeat = nullptr; bool valid = false; } init_hist[2];
     // intermediate taps (artalk_set_tap): parity tests compare these device buffers with intermediates captured from the reference
     float* tap = nullptr; int tap_B = 0, tap_maxch = 0, tap_chunk = 0;
     std::vector<uint32_t> cu_mask;    // artalk_set_cu_mask: the library's own streams are restricted to these compute units
@@ -704,6 +709,32 @@ void run_reencode(artalk_model* m, int B, hipStream_t s) {
     launch_bsq_history(w.enc_out, w.hist_bits, w.prev_fdec, w.msfeat, B, s, w.status);
     launch_vq_embed(w.msfeat, kNTok - 1, m->vq_w, m->vq_b, m->prev_lvl_pos + kE, w.prev_in, kNTok, 1, w.style_cond,
                     m->prev_lvl_pos, B, s);
+}
+
+// Initial history of B clips (app/models.py:86-89) from the per-model cache (artalk_model::init_hist).
+int run_init_history(artalk_model* m, int B, hipStream_t s) {
+    const artalk_config& c = m->cfg;
+    Workspace& w = m->ws;
+    artalk_model::InitHistory& ih = m->init_hist[m->precision == 1 ? 1 : 0];
+    const long nb = (long)kNTok * c.code_dim, nf = 100L * c.code_dim * 4, nm = 180L * c.code_dim * 4;
+    if (!ih.valid) {
+        if (!ih.bits) {
+            ih.bits = dalloc<uint8_t>(m, nb); ih.fdec = dalloc<float>(m, nf / 4); ih.msfeat = dalloc<float>(m, nm / 4);
+            if (!ih.bits || !ih.fdec || !ih.msfeat) return fail(m, ARTALK_EHIP, "hipMalloc failed for the initial-history cache");
+            HIPCHK(m, hipDeviceSynchronize());      // (dalloc's zero fill runs on the null stream)
+        }
+        launch_enc_input_zero(m->vae_mean, m->vae_std, m->enc_pos, w.enc_in, 1, s);
+        run_reencode(m, 1, s);
+        HIPCHK(m, hipMemcpyAsync(ih.bits, w.hist_bits, nb, hipMemcpyDeviceToDevice, s));
+        HIPCHK(m, hipMemcpyAsync(ih.fdec, w.prev_fdec, nf, hipMemcpyDeviceToDevice, s));
+        HIPCHK(m, hipMemcpyAsync(ih.msfeat, w.msfeat, nm, hipMemcpyDeviceToDevice, s));
+        ih.valid = true;
+    }
+    launch_broadcast16(ih.bits, w.hist_bits, nb, B, s);
+    launch_broadcast16(ih.fdec, w.prev_fdec, nf, B, s);
+    launch_broadcast16(ih.msfeat, w.msfeat, nm, B, s);
+    launch_vq_embed(w.msfeat, kNTok - 1, m->vq_w, m->vq_b, m->prev_lvl_pos + kE, w.prev_in, kNTok, 1, w.style_cond, m->prev_lvl_pos, B, s);
+    return ARTALK_OK;
 }
 
 // Everything of one chunk index that depends only on (B, fixed workspace pointers): capturable as one hipGraph.
@@ -1369,9 +1400,8 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
     // persistent one-workgroup-per-CU GEMM kernels, whose workgroups hold a CU's LDS for a whole launch, the body's short kernels wait
     // behind them - 82 -> 128 ms per step; removed)
     for (int c0 = 0; c0 < C; c0 += w.G) run_wav2vec(m, audio_dev, c0, (int)std::min<int64_t>(w.G, C - c0), out_w2v_dev, s);
-    // initial history: encode + quantise an all-zero motion (app/models.py:86-89)
-    launch_enc_input_zero(m->vae_mean, m->vae_std, m->enc_pos, w.enc_in, B, s);
-    run_reencode(m, B, s);
+    // initial history: encode + quantise an all-zero motion (app/models.py:86-89) - the same for every clip: cached per model
+    if (int rc = run_init_history(m, B, s)) return rc;
     const size_t bits_row = (size_t)kNTok * c.code_dim;
     if (out_hist_bits_dev)
         HIPCHK(m, hipMemcpy2DAsync(out_hist_bits_dev, (size_t)(maxch + 1) * bits_row, w.hist_bits, bits_row, bits_row, B,
@@ -1464,8 +1494,7 @@ int artalk_stream_begin(artalk_model* m, int B, const float* style_motion_dev, c
     {
         ProfilingOff quiet(m);
         run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s, encode_style);
-        launch_enc_input_zero(m->vae_mean, m->vae_std, m->enc_pos, w.enc_in, B, s);
-        run_reencode(m, B, s);
+        if (int rc = run_init_history(m, B, s)) return rc;
     }
     m->stream_B = B;
     if (int rc = publish_status(m, s)) return rc;

@@ -143,6 +143,7 @@ void launch_dec_finish(const float* dec /*[B*200,106]*/, const float* mean, cons
                        float* out, long out_bstride, int chunk, float* E, int B, hipStream_t s, int* status = nullptr);   // status |= 4: non-finite code
 // zero motion encoder input (initial history): E[b*100+t] = (0-mean)/std + epos[t]
 void launch_enc_input_zero(const float* mean, const float* stdv, const float* epos, float* E, int B, hipStream_t s);
+void launch_broadcast16(const void* src, void* dst, long bytes, int B, hipStream_t s);      // dst[b] = src for b < B (bytes % 16 == 0)
 // multi-scale BSQ of enc_out [B*100,32] -> hist bits [B,181,32], prev_fdec [B,100,32], ms feats [B,180,32]
 void launch_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fdec, float* msfeat, int B, hipStream_t s,
                         int* status = nullptr);    // status |= 2 if an encoder output is not finite

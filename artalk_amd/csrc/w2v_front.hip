@@ -102,8 +102,10 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
         for (int jj = 0; jj < 4; ++jj) o[jj] = gelu_erf2(__builtin_elementwise_fma((v[jj] - mean) * rstd, gw[jj], gb[jj]));
         float* y = Y + ((long)c * row_stride + t) * 512;
         if (out_p8) {
-            store_p8x4(y, lane * 4, o[0].x, o[0].y, o[1].x, o[1].y, status);
-            store_p8x4(y, 256 + lane * 4, o[2].x, o[2].y, o[3].x, o[3].y, status);
+            // adjacent lanes own the two halves of one 8-element P8 group: they trade halves and issue ONE 16-byte store each
+            // (2 store instructions per row and lane instead of 4)
+            store_p8x4_pair(y, lane * 4, o[0].x, o[0].y, o[1].x, o[1].y, status);
+            store_p8x4_pair(y, 256 + lane * 4, o[2].x, o[2].y, o[3].x, o[3].y, status);
         } else {
             f32x4 lo = {o[0].x, o[0].y, o[1].x, o[1].y}, hi = {o[2].x, o[2].y, o[3].x, o[3].y};
             *reinterpret_cast<f32x4*>(y + lane * 4) = lo;

@@ -10,6 +10,8 @@ s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for name, B, H, HD, Lq, Lk, l2, split in [("w2v", 96, 16, 64, 199, 199, 0, 0), ("ar p4", 16, 12, 64, 100, 362, 1, 0), ("ar p3", 16, 12, 64, 50, 262, 1, 0),
                                           ("ar p2", 16, 12, 64, 25, 212, 1, 0), ("ar p1", 16, 12, 64, 5, 187, 1, 0), ("ar p0", 16, 12, 64, 1, 182, 1, 0),
                                           ("vae dec", 16, 8, 64, 200, 200, 0, 100), ("vae enc", 16, 8, 64, 100, 100, 0, 0)]:
+    if os.environ.get("ATTN_ONLY") and name not in os.environ["ATTN_ONLY"].split(","):
+        continue
     D = H * HD
     Q = torch.randn(B, Lq, D, device="cuda"); K = torch.randn(B, Lk, D, device="cuda"); V = torch.randn(B, Lk, D, device="cuda")
     O = torch.empty(B, Lq, D, device="cuda"); qs = torch.ones(H, device="cuda")
