@@ -13,6 +13,7 @@
 //  * the S^T accumulator is directly the B operand of O^T += V^T P^T (guide section 3 "accumulator as next
 //    operand"): k-slot g of step j carries key 4g+j, and the V fragment is read with the same permutation.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace artalk {
@@ -809,6 +810,231 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
     }
 }
 
+// ---- Persistent ping-pong form of the wide kernel for the wav2vec2 encoder (199 x 199 per head, 1536 heads per launch).  The wide
+// kernel's launch is 6 rounds of (stage all keys: ~5 us of exposed global -> LDS traffic, 315 MB per launch in bursts) + (compute:
+// ~13 us); profiles/r04_attn_ablation.log: without the K / V loads the launch takes 79 instead of 108 us.  Here ONE workgroup per CU
+// walks heads, and the keys of a head live in two LDS buffers - A = keys 0..127, B = keys 128..223 (4 images each, 160-byte rows as
+// above: 80 + 60 KB) - filled by LDS-DMA (global_load_lds with per-lane source addresses: lane L of piece n supplies the 16-byte slot
+// 64 n + L of the image, i.e. chunk (64 n + L) % 10 of row (64 n + L) / 10; slots 8 and 9 of a row are its padding) while the waves
+// compute on the other buffer: B of this head is fetched under the first two 64-key blocks, A of the NEXT head (and its Q fragments)
+// under the last two.  No staging registers, no ds_write, two barriers per head.  The block loop is attention_f16_kernel's: same
+// blocks, same order, same arithmetic per query - bit-identical results (tests/test_ops_gpu.py).
+constexpr int kPPWaves = 13, kPPRowsA = 128, kPPRowsB = 96;
+// transposed 64-bit LDS reads of the V operand for one d tile: rows r1 / r1 + 16 of the hi image and of the lo image (LOFF bytes on)
+template <int OFF>
+__device__ __forceinline__ f16x4_t pp_read_tr(unsigned addr) {
+    f16x4_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int LOFF, int COL>
+__device__ __forceinline__ void pp_read_v(unsigned va, f16x4_t& a1, f16x4_t& a2, f16x4_t& b1, f16x4_t& b2) {
+    a1 = pp_read_tr<COL>(va);
+    a2 = pp_read_tr<16 * 160 + COL>(va);
+    b1 = pp_read_tr<LOFF + COL>(va);
+    b2 = pp_read_tr<LOFF + 16 * 160 + COL>(va);
+}
+template <int N>
+__device__ __forceinline__ void pp_wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int FASTEXP>
+__global__ __launch_bounds__(kPPWaves * 64) void attention_f16_pp_kernel(const AttnArgs a) {
+    constexpr int HD = 64, KB = 64, PB = 160;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pp_smem[];
+    unsigned char* const bufA = pp_smem;
+    unsigned char* const bufB = pp_smem + 4 * kPPRowsA * PB;
+
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int n_items = a.B * a.H;
+    const int q0 = wave * 16;
+    const int qi = q0 + r;
+    const bool qvalid = qi < a.Lq;
+    const bool wave_active = q0 < a.Lq;
+    const int trq = r >> 2, trp = r & 3;
+    const float sfix = a.scale / (kActScale * kActScale);
+
+    // one buffer of one head: 4 images x R rows, piece idx = (image, n) handled by wave idx % 13
+    auto issue_buffer = [&](int item, unsigned char* buf, const int R, int key0) {
+        const int b = item / a.H, h = item - b * a.H;
+        const unsigned char* Kb = reinterpret_cast<const unsigned char*>(a.K + (long)b * a.k_bstride + h * HD);
+        const unsigned char* Vb = reinterpret_cast<const unsigned char*>(a.V + (long)b * a.v_bstride + h * HD);
+        const int per = R * 10 / 64;
+        for (int idx = wave; idx < 4 * per; idx += kPPWaves) {
+            const int im = idx / per, n = idx - im * per;
+            const int ci = n * 64 + lane;
+            const int row = ci / 10, slot = ci - row * 10;
+            const int key = min(key0 + row, a.Lk - 1);               // rows past Lk: a copy of the last key (masked in the softmax; finite)
+            const int g8 = slot < 8 ? slot : 0;                       // padding slots: any valid 16 bytes
+            const unsigned char* src = (im < 2 ? Kb + (long)key * a.ldk * 4 : Vb + (long)key * a.ldv * 4) + g8 * 32 + (im & 1) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(buf + im * R * PB + n * 1024), 16, 0, 0);
+        }
+    };
+    auto load_q = [&](int item, h8_t (&qh)[2], h8_t (&ql)[2]) {
+        const int b = item / a.H, h = item - b * a.H;
+        const unsigned char* qp = reinterpret_cast<const unsigned char*>(a.Q + (long)b * a.q_bstride + (long)min(qi, a.Lq - 1) * a.ldq + h * HD);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {      // (raw: nothing consumes these before the end of the current head, so no wait is placed behind the loads)
+            qh[kb] = *reinterpret_cast<const h8_t*>(qp + (g + 4 * kb) * 32);
+            ql[kb] = *reinterpret_cast<const h8_t*>(qp + (g + 4 * kb) * 32 + 16);
+        }
+    };
+    const h8_t z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    h8_t qh[2], ql[2], qnh[2], qnl[2];
+    issue_buffer(item, bufA, kPPRowsA, 0);
+    load_q(item, qnh, qnl);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) { qh[kb] = qvalid ? qnh[kb] : z8; ql[kb] = qvalid ? qnl[kb] : z8; }      // rows past Lq: zero fragments
+    for (; item < n_items; item += gridDim.x) {
+        const int next = item + (int)gridDim.x;
+        float m_run = -INFINITY, l_part = 0.f;
+        f32x4 ot[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { f32x4 zz = {0.f, 0.f, 0.f, 0.f}; ot[d] = zz; }
+
+        // 64-key blocks [kfrom, kto) out of a buffer whose row 0 is key `key0`
+        auto phase = [&](const unsigned char* buf, auto r_tag, int key0, int kfrom, int kto) {
+            constexpr int R = decltype(r_tag)::value;
+            const unsigned char* const Kh = buf;
+            const unsigned char* const Kl = buf + R * PB;
+            const unsigned vh_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)(buf + 2 * R * PB);
+            for (int kb0 = kfrom; kb0 < kto; kb0 += KB) {
+                const int ntile = min(4, (a.Lk - kb0 + 15) >> 4);
+                const int rb = kb0 - key0;
+                f32x4 st[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    if (t < ntile) {
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb) {
+                            const int off = (rb + t * 16 + r) * PB + (8 * g + 32 * kb) * 2;
+                            const h8_t kh2 = *reinterpret_cast<const h8_t*>(Kh + off), kl2 = *reinterpret_cast<const h8_t*>(Kl + off);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh2, qh[kb], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl2, qh[kb], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh2, ql[kb], acc, 0, 0, 0);
+                        }
+                    }
+                    st[t] = acc;
+                }
+                float mx = -INFINITY;
+                if (kb0 + KB <= a.Lk) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float sv = st[t][j] * sfix;
+                            st[t][j] = sv;
+                            mx = fmaxf(mx, sv);
+                        }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int kidx = kb0 + t * 16 + 4 * g + j;
+                            const float sv = (kidx < a.Lk) ? st[t][j] * sfix : -INFINITY;
+                            st[t][j] = sv;
+                            mx = fmaxf(mx, sv);
+                        }
+                }
+                mx = fmaxf(mx, lane_xor<16>(mx));
+                mx = fmaxf(mx, lane_xor<32>(mx));
+                const float m_new = fmaxf(m_run, mx);
+                const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = FASTEXP ? __expf(m_run - m_safe) : expf(m_run - m_safe);
+                m_run = m_new;
+                float ps = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float p = FASTEXP ? __expf(st[t][j] - m_safe) : expf(st[t][j] - m_safe);
+                        st[t][j] = p;
+                        ps += p;
+                    }
+                l_part = l_part * alpha + ps;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) ot[d] *= alpha;
+#pragma unroll
+                for (int T = 0; T < 2; ++T) {
+                    if (2 * T < ntile) {
+                        f16x4_t h0, l0, h1, l1;
+                        split4(st[2 * T], h0, l0);
+                        split4(st[2 * T + 1], h1, l1);
+                        const h8_t ph = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                        const h8_t pl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                        // The 16 transposed V reads of this pair of tiles go out as asm (the builtin makes hipcc wait for the LDS-DMA in
+                        // flight - s_waitcnt vmcnt(0) in front of every read - which would serialise the fetch of the other buffer with
+                        // this arithmetic); their results return in order and are waited for with counted lgkmcnt, four reads per d tile.
+                        const unsigned va = vh_lds + (unsigned)((rb + T * 32 + 4 * g + trq) * PB + 8 * trp);
+                        auto pv = [&](int dt, const f16x4_t& x1, const f16x4_t& x2, const f16x4_t& y1, const f16x4_t& y2) {
+                            const h8_t vh2 = {x1[0], x1[1], x1[2], x1[3], x2[0], x2[1], x2[2], x2[3]};
+                            const h8_t vl2 = {y1[0], y1[1], y1[2], y1[3], y2[0], y2[1], y2[2], y2[3]};
+                            ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh2, ph, ot[dt], 0, 0, 0);
+                            ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl2, ph, ot[dt], 0, 0, 0);
+                            ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh2, pl, ot[dt], 0, 0, 0);
+                        };
+                        {      // d tiles 0, 1 then 2, 3: eight reads in flight at a time (16 registers; all sixteen at once spilled)
+                            f16x4_t a1[2], a2[2], b1[2], b2[2];
+                            pp_read_v<R * PB, 0>(va, a1[0], a2[0], b1[0], b2[0]);
+                            pp_read_v<R * PB, 32>(va, a1[1], a2[1], b1[1], b2[1]);
+                            pp_wait_lgkm<4>();
+                            pv(0, a1[0], a2[0], b1[0], b2[0]);
+                            pp_wait_lgkm<0>();
+                            pv(1, a1[1], a2[1], b1[1], b2[1]);
+                        }
+                        {
+                            f16x4_t a1[2], a2[2], b1[2], b2[2];
+                            pp_read_v<R * PB, 64>(va, a1[0], a2[0], b1[0], b2[0]);
+                            pp_read_v<R * PB, 96>(va, a1[1], a2[1], b1[1], b2[1]);
+                            pp_wait_lgkm<4>();
+                            pv(2, a1[0], a2[0], b1[0], b2[0]);
+                            pp_wait_lgkm<0>();
+                            pv(3, a1[1], a2[1], b1[1], b2[1]);
+                        }
+                    }
+                }
+            }
+        };
+
+        __syncthreads();                 // A of this head has landed for every wave (vmcnt(0) + barrier); everyone is done with B of the previous head
+        issue_buffer(item, bufB, kPPRowsB, kPPRowsA);
+        if (wave_active) phase(bufA, std::integral_constant<int, kPPRowsA>{}, 0, 0, min(a.Lk, kPPRowsA));
+        __syncthreads();                 // B has landed; everyone is done with A
+        if (next < n_items) {
+            issue_buffer(next, bufA, kPPRowsA, 0);
+            load_q(next, qnh, qnl);
+        }
+        if (wave_active) {
+            phase(bufB, std::integral_constant<int, kPPRowsB>{}, kPPRowsA, kPPRowsA, a.Lk);
+            float l = l_part;
+            l += lane_xor<16>(l);
+            l += lane_xor<32>(l);
+            if (qvalid) {
+                const int b = item / a.H, h = item - b * a.H;
+                const float inv = 1.0f / (l * kActScale);      // P8 values carry x16
+                float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int d0 = 16 * dt + 4 * g;
+                    const float o0 = ot[dt][0] * inv, o1 = ot[dt][1] * inv, o2 = ot[dt][2] * inv, o3 = ot[dt][3] * inv;
+                    if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status);
+                    else { const f32x4 o = {o0, o1, o2, o3}; *reinterpret_cast<f32x4*>(op + d0) = o; }
+                }
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { qh[kb] = qvalid ? qnh[kb] : z8; ql[kb] = qvalid ? qnl[kb] : z8; }
+    }
+}
+
 // ---- The same idea for the 100-query scale step of the AR decoder (fp32 q | k | v rows of the KV cache, L2-normalised q and k,
 // 362 keys): one workgroup of 7 waves per (clip, head) stages 192 keys at a time (K and V, hi and lo images: 120 KB) - two staging
 // round trips per head instead of six per 64-query workgroup, and the normalise + split work of a key done once instead of twice.
@@ -1094,6 +1320,8 @@ void attention_prepare() {      // more than the default 64 KB of dynamic LDS fo
     if (dev < 0 || dev >= 64 || done[dev]) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               4 * kWideMaxKeys * 160);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_pp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              4 * (kPPRowsA + kPPRowsB) * 160);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_wide_ar_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               4 * kWideArKeys * 160);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_wide_ar_kernel<1, 1, 7, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1114,6 +1342,15 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         attention_prepare();
         // fewer (clip, head) pairs than CUs (the VAE stacks of one clip group: 128): two 7-wave workgroups per head, 128 keys per phase
         // (14.1 -> 11.9 us); the encoder's 1536 pairs run the same either way (109 us: bound by the softmax arithmetic, not by staging)
+        // ARTALK_ATTN_PP [1]: the persistent ping-pong kernel where every CU gets several heads (the encoder); 0 = the one-head-per-workgroup kernel
+        static const int pp = getenv("ARTALK_ATTN_PP") ? atoi(getenv("ARTALK_ATTN_PP")) : 1;
+        static int n_cu = 0;
+        if (!n_cu && (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || n_cu <= 0)) n_cu = 256;
+        const int cus = a.cus > 0 ? (a.cus < n_cu ? a.cus : n_cu) : n_cu;
+        if (pp && wide != 2 && a.split_q <= 0 && a.Lk > kPPRowsA && a.Lk <= kPPRowsA + kPPRowsB && (long)a.B * a.H >= 2L * cus) {
+            hipLaunchKernelGGL((attention_f16_pp_kernel<1>), dim3(cus), dim3(kPPWaves * 64), (size_t)4 * (kPPRowsA + kPPRowsB) * 160, s, a);
+            return;
+        }
         if (wide == 2 || (long)a.B * a.H < 256) hipLaunchKernelGGL((attention_f16_wide_ar_kernel<1, 1, 7, 128>), dim3((a.Lq + 111) / 112, a.H, a.B), dim3(7 * 64), (size_t)4 * 128 * 160, s, a);
         else hipLaunchKernelGGL((attention_f16_wide_kernel<1>), dim3(1, a.H, a.B), dim3(kWideMaxWaves * 64), lds, s, a);
     } else if (a.HD == 64 && a.split16 && a.qkv_p8 && !a.l2norm)

@@ -75,7 +75,7 @@ struct Workspace {
     float *h0 = nullptr, *h1 = nullptr, *xln = nullptr, *qkv = nullptr, *att = nullptr, *ffn = nullptr;
     float* silu_cond = nullptr;     // [maxC*181, 1024]
     // AR
-    float *ada = nullptr, *style_cond = nullptr, *prev_in = nullptr, *prev_in_p8 = nullptr, *cache = nullptr;
+    float *ada = nullptr, *ada2 = nullptr, *style_cond = nullptr, *prev_in = nullptr, *prev_in_p8 = nullptr, *cache = nullptr;
     float *x = nullptr, *xmod = nullptr, *attn_out = nullptr, *ffn_h = nullptr, *logits = nullptr;
     float *fhat = nullptr, *nextfeat = nullptr;
     float* splitk = nullptr; int64_t splitk_floats = 0;   // partial sums of split-K GEMMs
@@ -152,6 +152,16 @@ struct artalk_model {
     std::vector<std::pair<int, size_t>> marks;          // (bucket of the interval ending here, event index), caller's stream
     hipStream_t prof_stream = nullptr;
     hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};   // extra branches of the AR body (run_chunk_body_graphs)
+    // Overlapped AdaLN tables (artalk_infer): the table of chunk index j + 1 does not depend on the AR state, so its GEMM runs on a
+    // stream of its own, on a REDUCED grid (ada_cus of the CUs: a persistent workgroup holds its CU for the whole launch, the free CUs
+    // are what the body's small kernels run on), beside the latency-bound first scale steps of body j; two tables (Workspace::ada / ada2).
+    // MEASURED, NOT A GAIN (round 4, same box, profiles/r04_ada_overlap_sweep.log): in line 5.0 + 31.7 ms (tables + bodies), overlapped on
+    // 128 / 192 / 256 CUs 1.7 + 37.0 / 36.2 / 35.1 ms - the bodies slow down by what the table GEMM takes (its 3 TB/s of operand and
+    // result traffic and its hold on the CUs land on exactly the launches whose time is memory latency).  Off by default
+    // (ARTALK_ADA_OVERLAP=1 switches it on for an A/B run; the second table is only allocated then).
+    bool ada_overlap = false; int ada_cus = 192, cus_override = 0;
+    hipStream_t ada_stream = nullptr;
+    hipEvent_t ada_done[2] = {nullptr, nullptr}, body_done[2] = {nullptr, nullptr}, ada_pre = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
     int branches = 0;                 // 0 = automatic (2 for B >= 8), else forced 1/2/4
     hipStream_t own_stream = nullptr;   // used when the caller passes stream == NULL (graph capture needs a real stream)
@@ -422,7 +432,7 @@ void audit(artalk_model* m, const std::string& site, const float* buf, int rows,
 bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse_ln = nullptr) {
     GemmArgs g = g0;
     g.graph_tag = m->in_body ? 1 : 0;
-    g.cus = m->n_cus;
+    g.cus = m->cus_override > 0 ? (m->n_cus > 0 ? std::min(m->cus_override, m->n_cus) : m->cus_override) : m->n_cus;
     g.status = m->precision == 1 ? (m->view ? m->view->status : m->ws.status) : nullptr;     // P8 range guard at the producers
     bool split = false;
     if (m->precision == 1 && !g.exact) {
@@ -610,7 +620,7 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
         a.O = w.att; a.ldo = Hs; a.o_bstride = (long)m->Ts * Hs;
         a.B = n; a.H = nh; a.HD = hd; a.Lq = m->Tw; a.Lk = m->Tw; a.scale = 1.0f / std::sqrt((float)hd);
         audit(m, an + ".qkv", w.qkv, M, 3 * Hs, 3 * Hs, p8, s, JP, JF);
-        a.out_p8 = p8; a.split16 = p8; a.status = p8 ? w.status : nullptr;
+        a.out_p8 = p8; a.split16 = p8; a.status = p8 ? w.status : nullptr; a.cus = m->n_cus;
         launch_attention(a, s);
         audit(m, an + ".attn_out", w.att, M, Hs, Hs, p8, s, JP, JF);
         linear(m, w.att, Hs, L.out_w, L.out_b, h, Hs, M, Hs, Hs, ACT_NONE, h, s, AP);
@@ -861,10 +871,11 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
 
 // A view of the workspace for clips [b0, ...): every per-clip buffer pointer advanced by b0 clips (compact step buffers get a
 // fixed 100-row region per clip so the two halves never overlap), its own split-K scratch.
-Workspace clip_view(const artalk_model* m, int b0, int branch) {
+Workspace clip_view(const artalk_model* m, int b0, int branch, int parity = 0) {
     const artalk_config& c = m->cfg;
     Workspace v = m->ws;
     const long b = b0;
+    if (parity && v.ada2) v.ada = v.ada2;       // (the table this chunk index reads: artalk_infer's overlapped AdaLN schedule)
     v.ada += b * kNTok * m->ada_n; v.style_cond += b * kE; v.prev_in += b * kNTok * kE; v.prev_in_p8 += b * kNTok * kE;
     v.cache += b * 2 * kNTok * 3 * kE;
     v.x += b * 100 * kE; v.xmod += b * 100 * kE; v.attn_out += b * 100 * kE; v.ffn_h += b * 100 * 4 * kE;
@@ -917,7 +928,7 @@ int body_branches(const artalk_model* m, int B) {
     const int want = m->branches > 0 ? m->branches : (B >= 8 ? 2 : 1);
     return B >= 2 * want ? want : (B >= 8 ? 2 : 1);
 }
-int run_chunk_body_graphs(artalk_model* m, int B, hipStream_t s) {
+int run_chunk_body_graphs(artalk_model* m, int B, hipStream_t s, int parity = 0) {
     const int NS = body_branches(m, B);
     if (NS > 1) { if (int rc = ensure_side_streams(m, NS - 1)) return rc; }
     Workspace views[4];
@@ -925,14 +936,14 @@ int run_chunk_body_graphs(artalk_model* m, int B, hipStream_t s) {
     for (int h = 0; h <= NS; ++h) b0[h] = (int)((long)B * h / NS);
     hipStream_t st[4] = {s, m->side_stream[0], m->side_stream[1], m->side_stream[2]};
     for (int h = 0; h < NS; ++h) {
-        views[h] = clip_view(m, b0[h], h);
-        const int key = ((B * 8 + NS) * 4 + h) * 2 + m->precision;
+        views[h] = clip_view(m, b0[h], h, parity);
+        const int key = (((B * 8 + NS) * 4 + h) * 2 + m->precision) * 2 + parity;
         if (m->graphs.find(key) != m->graphs.end()) continue;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         HIPCHK(m, hipStreamBeginCapture(st[h], hipStreamCaptureModeThreadLocal));
         m->in_graph_body = true;
-        m->view = NS > 1 ? &views[h] : nullptr;
+        m->view = &views[h];
         run_chunk_body(m, b0[h + 1] - b0[h], st[h]);
         m->view = nullptr;
         m->in_graph_body = false;
@@ -945,7 +956,7 @@ int run_chunk_body_graphs(artalk_model* m, int B, hipStream_t s) {
         HIPCHK(m, hipEventRecord(m->fork_ev, s));
         for (int h = 1; h < NS; ++h) HIPCHK(m, hipStreamWaitEvent(st[h], m->fork_ev, 0));
     }
-    for (int h = 0; h < NS; ++h) HIPCHK(m, hipGraphLaunch(m->graphs[((B * 8 + NS) * 4 + h) * 2 + m->precision], st[h]));
+    for (int h = 0; h < NS; ++h) HIPCHK(m, hipGraphLaunch(m->graphs[(((B * 8 + NS) * 4 + h) * 2 + m->precision) * 2 + parity], st[h]));
     for (int h = 1; h < NS; ++h) {
         HIPCHK(m, hipEventRecord(m->join_ev[h - 1], st[h]));
         HIPCHK(m, hipStreamWaitEvent(s, m->join_ev[h - 1], 0));
@@ -1024,6 +1035,7 @@ int reserve(artalk_model* m, int maxB, int maxC) {
     w.h0 = F(M * Hs); w.h1 = F(M * Hs); w.xln = F(M * Hs); w.qkv = F(M * 3 * Hs); w.att = F(M * Hs); w.ffn = F(M * c.w2v_ffn);
     w.silu_cond = F((int64_t)maxC * kNTok * kCond);
     w.ada = F((int64_t)maxB * kNTok * m->ada_n);
+    if (m->ada_overlap) w.ada2 = F((int64_t)maxB * kNTok * m->ada_n);      // the table of chunk index j + 1 is written while the body of index j reads its own
     w.style_cond = F((int64_t)maxB * kE);
     w.prev_in = F((int64_t)maxB * kNTok * kE); w.prev_in_p8 = F((int64_t)maxB * kNTok * kE);
     w.cache = F((int64_t)c.ar_depth * maxB * 2 * kNTok * 3 * kE);
@@ -1072,6 +1084,8 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return ARTALK_EHIP; }
     artalk_model* m = new artalk_model();
     m->cfg = c; m->device = device_id;
+    if (const char* e = getenv("ARTALK_ADA_OVERLAP")) m->ada_overlap = atoi(e) != 0;      // A/B switch: 0 = the table GEMM in line, in front of every body
+    if (const char* e = getenv("ARTALK_ADA_CUS")) m->ada_cus = std::max(8, atoi(e));
     // conv stack geometry: T_l valid frames; row stride S_l per chunk with S_l = 2*S_{l+1} so that one GEMM covers all chunks
     int T = kSamplesPerChunk;
     for (int i = 0; i < c.w2v_n_conv; ++i) { T = (T - c.w2v_conv_kernel[i]) / c.w2v_conv_stride[i] + 1; m->conv_T[i] = T; }
@@ -1106,6 +1120,9 @@ void artalk_destroy(artalk_model* m) {
         if (m->join_ev[i]) (void)hipEventDestroy(m->join_ev[i]);
     }
     if (m->fork_ev) (void)hipEventDestroy(m->fork_ev);
+    if (m->ada_stream) (void)hipStreamDestroy(m->ada_stream);
+    for (int i = 0; i < 2; ++i) { if (m->ada_done[i]) (void)hipEventDestroy(m->ada_done[i]); if (m->body_done[i]) (void)hipEventDestroy(m->body_done[i]); }
+    if (m->ada_pre) (void)hipEventDestroy(m->ada_pre);
     free_stage(m);
     for (auto& st : m->stage) if (st.done) (void)hipEventDestroy(st.done);
     if (m->h_status) (void)hipHostFree(m->h_status);
@@ -1342,6 +1359,12 @@ int artalk_set_cu_mask(artalk_model* m, const uint32_t* mask, int n_words) {
         if (m->side_stream[i]) { (void)hipStreamDestroy(m->side_stream[i]); m->side_stream[i] = nullptr; }
         if (m->join_ev[i]) { (void)hipEventDestroy(m->join_ev[i]); m->join_ev[i] = nullptr; }
     }
+    if (m->ada_stream) { (void)hipStreamDestroy(m->ada_stream); m->ada_stream = nullptr; }      // re-created (masked) on demand, with its events
+    for (int i = 0; i < 2; ++i) {
+        if (m->ada_done[i]) { (void)hipEventDestroy(m->ada_done[i]); m->ada_done[i] = nullptr; }
+        if (m->body_done[i]) { (void)hipEventDestroy(m->body_done[i]); m->body_done[i] = nullptr; }
+    }
+    if (m->ada_pre) { (void)hipEventDestroy(m->ada_pre); m->ada_pre = nullptr; }
     for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);      // the GEMM grids were captured for the old CU count
     m->graphs.clear();
     return ARTALK_OK;
@@ -1409,19 +1432,56 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
     stage_mark(m, s, PB_VAE);
     const bool graphs = m->use_graphs && m->profiling != 2 && !m->audit && !m->tap;
     if (m->tap && (B > m->tap_B || maxch > m->tap_maxch)) return fail(m, ARTALK_EINVAL, "the tap buffer (artalk_set_tap) is smaller than this call");
+    // AdaLN table of a chunk index for all blocks + head: SiLU(cond) @ [W_0;...;W_11;W_head]^T.  Overlapped schedule (graphs on, two
+    // tables): the table of index j + 1 is computed on ada_stream, on ada_cus of the CUs, while body j runs - the body starts with its
+    // latency-bound scale steps 0-2, which leave most CUs idle.  Table j + 2 reuses the buffer of table j: it waits for body j.
+    const bool overlap = graphs && m->ada_overlap && w.ada2 && maxch > 1;
+    if (overlap) {
+        if (!m->ada_stream) {
+            if (m->cu_mask.empty()) HIPCHK(m, hipStreamCreateWithFlags(&m->ada_stream, hipStreamNonBlocking));
+            else HIPCHK(m, hipExtStreamCreateWithCUMask(&m->ada_stream, (uint32_t)m->cu_mask.size(), m->cu_mask.data()));
+            for (int i = 0; i < 2; ++i) {
+                HIPCHK(m, hipEventCreateWithFlags(&m->ada_done[i], hipEventDisableTiming));
+                HIPCHK(m, hipEventCreateWithFlags(&m->body_done[i], hipEventDisableTiming));
+            }
+            HIPCHK(m, hipEventCreateWithFlags(&m->ada_pre, hipEventDisableTiming));
+        }
+        HIPCHK(m, hipEventRecord(m->ada_pre, s));                       // wav2vec2 (silu_cond) is complete, the previous call is done with both tables
+        HIPCHK(m, hipStreamWaitEvent(m->ada_stream, m->ada_pre, 0));
+    }
+    auto ada_table = [&](int64_t j, hipStream_t st, float* dst, int cus) {
+        roctxRangePushA("artalk.ar.adaln_table");
+        m->cus_override = cus;
+        linear(m, w.silu_cond + (long)base[j] * kNTok * kCond, kCond, m->ada_w, m->ada_b, dst, m->ada_n, Bj[j] * kNTok, m->ada_n, kCond,
+               ACT_NONE, nullptr, st, m->precision == 1 ? LF_A_P8 : 0);
+        m->cus_override = 0;
+        roctxRangePop();
+    };
+    auto enqueue_ada = [&](int64_t j) -> int {       // (overlapped schedule) table j on ada_stream
+        if (j >= maxch) return ARTALK_OK;
+        if (j >= 2) HIPCHK(m, hipStreamWaitEvent(m->ada_stream, m->body_done[j & 1], 0));      // body j - 2 has read this buffer
+        ada_table(j, m->ada_stream, (j & 1) ? w.ada2 : w.ada, j == 0 ? 0 : m->ada_cus);         // table 0 has the chip to itself
+        HIPCHK(m, hipEventRecord(m->ada_done[j & 1], m->ada_stream));
+        return ARTALK_OK;
+    };
+    if (overlap) {
+        if (int rc = enqueue_ada(0)) return rc;
+        if (int rc = enqueue_ada(1)) return rc;
+    }
     for (int64_t j = 0; j < maxch; ++j) {
         const int Bn = Bj[j];
         m->tap_chunk = (int)j;
-        // AdaLN table of this chunk index for all blocks + head: SiLU(cond) @ [W_0;...;W_11;W_head]^T
-        roctxRangePushA("artalk.ar.adaln_table");
-        linear(m, w.silu_cond + (long)base[j] * kNTok * kCond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, Bn * kNTok, m->ada_n, kCond,
-               ACT_NONE, nullptr, s, m->precision == 1 ? LF_A_P8 : 0);
-        stage_mark(m, s, PB_ADA);
-        roctxRangePop();
+        if (overlap) HIPCHK(m, hipStreamWaitEvent(s, m->ada_done[j & 1], 0));
+        else ada_table(j, s, w.ada, 0);
+        stage_mark(m, s, PB_ADA);       // (overlapped schedule: the time this stream WAITED for the table)
         if (graphs) {
             Range r_body("artalk.body.graph");
-            if (int brc = run_chunk_body_graphs(m, Bn, s)) return brc;
+            if (int brc = run_chunk_body_graphs(m, Bn, s, overlap ? (int)(j & 1) : 0)) return brc;
             stage_mark(m, s, PB_AR);   // light profiling: the whole captured body (AR steps + VAE) is charged to the AR bucket
+            if (overlap) {
+                HIPCHK(m, hipEventRecord(m->body_done[j & 1], s));
+                if (int rc = enqueue_ada(j + 2)) return rc;
+            }
         } else {
             if (int brc = run_chunk_body_split(m, Bn, s)) return brc;
         }

@@ -612,6 +612,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
                 wait_lgkmcnt<0>();
                 if (next_top) top(buf ^ 1, next_pre);      // (slot 0 and the k-block-0 weight fragments are free: this sub-step uses slot 1 / k block 1)
             }
+#ifdef BIG_SETPRIO      // (experiment: the wave whose fragments are in gets the issue slots for its six MFMAs)
+            __builtin_amdgcn_s_setprio(BIG_SETPRIO);
+#endif
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -632,6 +635,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+#ifdef BIG_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     };

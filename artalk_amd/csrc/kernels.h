@@ -112,6 +112,7 @@ struct AttnArgs {
     int split16 = 0;                                 // 1: fp16 operand-split MFMAs (f16x3 mode), 0: exact fp32 MFMAs
     int qkv_p8 = 0;                                  // 1 (with split16, no l2norm): Q, K, V rows are in the P8 split format (written so by the qkv GEMM)
     int* status = nullptr;                           // out_p8: range guard (see GemmArgs::status)
+    int cus = 0;                                     // compute units of the model's partition (0 = the whole device): grid of the persistent kernel
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 void attention_prepare();      // one-time kernel attributes (call once per process before the first captured launch)

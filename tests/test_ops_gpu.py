@@ -396,11 +396,14 @@ np.save(sys.argv[2], out.cpu().numpy())
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,split,mode", [(3, 16, 199, 199, 0, "p8"), (2, 8, 200, 200, 100, "p8"), (2, 8, 100, 100, 0, "p8"), (20, 16, 199, 199, 0, "p8"),
-                                                  (3, 12, 100, 362, 0, "ar"), (2, 12, 97, 181, 0, "ar")])
+                                                  (3, 12, 100, 362, 0, "ar"), (2, 12, 97, 181, 0, "ar"),
+                                                  # >= 2 heads per CU: the persistent ping-pong kernel (attention_f16_pp_kernel): the encoder's shape with a ragged
+                                                  # last round, the largest shape it takes, few queries (idle waves), the shortest second buffer
+                                                  (40, 16, 199, 199, 0, "p8"), (33, 16, 208, 224, 0, "p8"), (36, 16, 150, 170, 0, "p8"), (32, 16, 199, 129, 0, "p8")])
 def test_attention_wide_kernel_is_bit_identical(tmp_path, B, H, Lq, Lk, split, mode):
-    """attention_f16_wide_kernel / attention_f16_wide_ar_kernel (one workgroup per (clip, head), keys staged once / 192 at a time)
-    must give bit for bit what the 64-query kernel gives: the switch is read once per process, so each arm runs in a child process
-    (ARTALK_ATTN_WIDE=1 / 0)."""
+    """attention_f16_wide_kernel / attention_f16_wide_ar_kernel (one workgroup per (clip, head), keys staged once / 192 at a time) and
+    attention_f16_pp_kernel (persistent, keys in two LDS buffers filled by LDS-DMA under the arithmetic) must give bit for bit what
+    the 64-query kernel gives: the switch is read once per process, so each arm runs in a child process (ARTALK_ATTN_WIDE=1 / 0)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
