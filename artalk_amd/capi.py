@@ -147,12 +147,13 @@ def lib() -> C.CDLL:
     L.artalk_op_pack_split.restype = i32
     L.artalk_op_gemm_f16s_packed.argtypes = [vp, i32, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.artalk_op_gemm_f16s_packed.restype = i32
-    L.artalk_set_tap.argtypes = [vp, vp, i32, i32]
-    L.artalk_set_tap.restype = i32
-    L.artalk_tap_layout.argtypes = [C.POINTER(C.c_int64), i32]
-    L.artalk_tap_layout.restype = i32
-    L.artalk_op_release_scratch.argtypes = []
-    L.artalk_op_release_scratch.restype = i32
+    if hasattr(L, "artalk_set_tap"):      # (an older build loaded through ARTALK_LIB for a same-box A/B run lacks the round-4 entry points)
+        L.artalk_set_tap.argtypes = [vp, vp, i32, i32]
+        L.artalk_set_tap.restype = i32
+        L.artalk_tap_layout.argtypes = [C.POINTER(C.c_int64), i32]
+        L.artalk_tap_layout.restype = i32
+        L.artalk_op_release_scratch.argtypes = []
+        L.artalk_op_release_scratch.restype = i32
     L.artalk_set_cu_mask.argtypes = [vp, vp, i32]
     L.artalk_set_cu_mask.restype = i32
     L.artalk_op_create_masked_stream.argtypes = [vp, i32, C.POINTER(vp)]

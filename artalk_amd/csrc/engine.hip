@@ -166,7 +166,7 @@ struct artalk_model {
     int branches = 0;                 // 0 = automatic (2 for B >= 8), else forced 1/2/4
     hipStream_t own_stream = nullptr;   // used when the caller passes stream == NULL (graph capture needs a real stream)
     // graphs: one per (active batch size, clip group, precision)
-    std::map<int, hipGraphExec_t> graphs;
+    std::map<long long, hipGraphExec_t> graphs;
     // Pinned host staging for the small per-call tables (chunk offsets, style flags): a ring of slots, each guarded by an event
     // recorded after its H2D copies, so artalk_infer never has to wait for its own copies (it blocks only if kStageSlots calls
     // are still in flight).  h_status receives the device status word at the end of every call (async), status_ev marks it.
@@ -748,7 +748,9 @@ int run_init_history(artalk_model* m, int B, hipStream_t s) {
 }
 
 // Everything of one chunk index that depends only on (B, fixed workspace pointers): capturable as one hipGraph.
-void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
+// n_reencode: clips (a prefix of the B) whose generated motion is re-encoded into the next history - the clips that HAVE a next chunk.
+// The reference re-encodes after every chunk (app/models.py:111-114), the last one included, and throws that result away.
+void run_chunk_body(artalk_model* m, int B, hipStream_t s, int n_reencode = -1) {
     struct BodyScope { artalk_model* m; BodyScope(artalk_model* x) : m(x) { m->in_body = true; } ~BodyScope() { m->in_body = false; } } scope(m);
     const artalk_config& c = m->cfg;
     Workspace& w = m->view ? *m->view : m->ws;
@@ -865,7 +867,8 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s) {
     launch_dec_finish(w.dec_out, m->vae_mean, m->vae_std, m->enc_pos, w.motion_chunk, 100L * c.motion_dim, 0, w.enc_in, B, s, w.status);
     roctxRangePop();
     // ---- re-encode the generated motion into the next history (app/models.py:111-114) ----
-    run_reencode(m, B, s);
+    if (n_reencode < 0 || n_reencode > B) n_reencode = B;
+    if (n_reencode > 0) run_reencode(m, n_reencode, s);
     stage_mark(m, s, PB_VAE);
 }
 
@@ -894,15 +897,16 @@ Workspace clip_view(const artalk_model* m, int b0, int branch, int parity = 0) {
 // for B >= 8 the batch is cut into two halves that run as parallel branches (stream s and m->side_stream; inside a capture this
 // becomes a fork/join in the hipGraph): one half's GPU-filling step overlaps the other half's latency-bound ones.
 int ensure_side_streams(artalk_model* m, int n);
-int run_chunk_body_split(artalk_model* m, int B, hipStream_t s) {
-    if (B < 8 || m->profiling == 2 || m->branches == 1 || m->audit || m->tap) { run_chunk_body(m, B, s); return ARTALK_OK; }
+int run_chunk_body_split(artalk_model* m, int B, hipStream_t s, int n_next = -1) {
+    if (n_next < 0 || n_next > B) n_next = B;
+    if (B < 8 || m->profiling == 2 || m->branches == 1 || m->audit || m->tap) { run_chunk_body(m, B, s, n_next); return ARTALK_OK; }
     if (int rc = ensure_side_streams(m, 1)) return rc;
     const int B0 = (B + 1) / 2, B1 = B - B0;
     Workspace v0 = clip_view(m, 0, 0), v1 = clip_view(m, B0, 1);
     HIPCHK(m, hipEventRecord(m->fork_ev, s));
     HIPCHK(m, hipStreamWaitEvent(m->side_stream[0], m->fork_ev, 0));
-    m->view = &v0; run_chunk_body(m, B0, s);
-    m->view = &v1; run_chunk_body(m, B1, m->side_stream[0]);
+    m->view = &v0; run_chunk_body(m, B0, s, std::min(n_next, B0));
+    m->view = &v1; run_chunk_body(m, B1, m->side_stream[0], std::max(0, n_next - B0));
     m->view = nullptr;
     HIPCHK(m, hipEventRecord(m->join_ev[0], m->side_stream[0]));
     HIPCHK(m, hipStreamWaitEvent(s, m->join_ev[0], 0));
@@ -928,23 +932,28 @@ int body_branches(const artalk_model* m, int B) {
     const int want = m->branches > 0 ? m->branches : (B >= 8 ? 2 : 1);
     return B >= 2 * want ? want : (B >= 8 ? 2 : 1);
 }
-int run_chunk_body_graphs(artalk_model* m, int B, hipStream_t s, int parity = 0) {
+int run_chunk_body_graphs(artalk_model* m, int B, hipStream_t s, int parity = 0, int n_next = -1) {
+    if (n_next < 0 || n_next > B) n_next = B;
+    if (B > 4095) { run_chunk_body(m, B, s, n_next); return ARTALK_OK; }      // (graph keys hold 12 bits of clip counts)
     const int NS = body_branches(m, B);
     if (NS > 1) { if (int rc = ensure_side_streams(m, NS - 1)) return rc; }
     Workspace views[4];
     int b0[5];
     for (int h = 0; h <= NS; ++h) b0[h] = (int)((long)B * h / NS);
     hipStream_t st[4] = {s, m->side_stream[0], m->side_stream[1], m->side_stream[2]};
+    long long keys[4];
     for (int h = 0; h < NS; ++h) {
         views[h] = clip_view(m, b0[h], h, parity);
-        const int key = (((B * 8 + NS) * 4 + h) * 2 + m->precision) * 2 + parity;
+        const int nre = std::max(0, std::min(n_next - b0[h], b0[h + 1] - b0[h]));      // clips of this group that have a next chunk
+        const long long key = ((long long)((((B * 8 + NS) * 4 + h) * 2 + m->precision) * 2 + parity)) * 4096 + nre;
+        keys[h] = key;
         if (m->graphs.find(key) != m->graphs.end()) continue;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         HIPCHK(m, hipStreamBeginCapture(st[h], hipStreamCaptureModeThreadLocal));
         m->in_graph_body = true;
         m->view = &views[h];
-        run_chunk_body(m, b0[h + 1] - b0[h], st[h]);
+        run_chunk_body(m, b0[h + 1] - b0[h], st[h], nre);
         m->view = nullptr;
         m->in_graph_body = false;
         HIPCHK(m, hipStreamEndCapture(st[h], &graph));
@@ -956,7 +965,7 @@ int run_chunk_body_graphs(artalk_model* m, int B, hipStream_t s, int parity = 0)
         HIPCHK(m, hipEventRecord(m->fork_ev, s));
         for (int h = 1; h < NS; ++h) HIPCHK(m, hipStreamWaitEvent(st[h], m->fork_ev, 0));
     }
-    for (int h = 0; h < NS; ++h) HIPCHK(m, hipGraphLaunch(m->graphs[(((B * 8 + NS) * 4 + h) * 2 + m->precision) * 2 + parity], st[h]));
+    for (int h = 0; h < NS; ++h) HIPCHK(m, hipGraphLaunch(m->graphs[keys[h]], st[h]));
     for (int h = 1; h < NS; ++h) {
         HIPCHK(m, hipEventRecord(m->join_ev[h - 1], st[h]));
         HIPCHK(m, hipStreamWaitEvent(s, m->join_ev[h - 1], 0));
@@ -1471,19 +1480,22 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
     for (int64_t j = 0; j < maxch; ++j) {
         const int Bn = Bj[j];
         m->tap_chunk = (int)j;
+        // clips whose motion must be re-encoded into a history: those with a chunk j + 1 (a prefix: clips are sorted by length) - all of
+        // them when the caller asked for the history bits of every chunk (the reference computes the trailing ones too and drops them)
+        const int n_next = out_hist_bits_dev ? Bn : (j + 1 < maxch ? Bj[j + 1] : 0);
         if (overlap) HIPCHK(m, hipStreamWaitEvent(s, m->ada_done[j & 1], 0));
         else ada_table(j, s, w.ada, 0);
         stage_mark(m, s, PB_ADA);       // (overlapped schedule: the time this stream WAITED for the table)
         if (graphs) {
             Range r_body("artalk.body.graph");
-            if (int brc = run_chunk_body_graphs(m, Bn, s, overlap ? (int)(j & 1) : 0)) return brc;
+            if (int brc = run_chunk_body_graphs(m, Bn, s, overlap ? (int)(j & 1) : 0, n_next)) return brc;
             stage_mark(m, s, PB_AR);   // light profiling: the whole captured body (AR steps + VAE) is charged to the AR bucket
             if (overlap) {
                 HIPCHK(m, hipEventRecord(m->body_done[j & 1], s));
                 if (int rc = enqueue_ada(j + 2)) return rc;
             }
         } else {
-            if (int brc = run_chunk_body_split(m, Bn, s)) return brc;
+            if (int brc = run_chunk_body_split(m, Bn, s, n_next)) return brc;
         }
         const size_t mrow = (size_t)100 * c.motion_dim * 4;
         HIPCHK(m, hipMemcpy2DAsync(out_motion_dev + j * 100 * c.motion_dim, (size_t)out_clip_stride * 4, w.motion_chunk, mrow, mrow, Bn,

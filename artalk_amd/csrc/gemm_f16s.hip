@@ -1675,16 +1675,18 @@ bool gemm_p8_sm_eligible(const GemmArgs& g) {
 // (128 KiB, one workgroup per CU), 24: 64x64 x 5 stages (80 KiB, two per CU).  (128x64, 64x128 and 128x128 tiles and a 3-stage ring
 // were measured on the unsplit grids of the 50- / 100-token steps and never won: DESIGN.md section 6.)
 void gemm_p8_prepare();
+template <int STAGES>
 static void launch_p8_mid(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     gemm_p8_prepare();
-    if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_mid_kernel<4, 1>), dim3(tiles, g.splitk), dim3(512), 4 * 256 * 128, s, g);
-    else hipLaunchKernelGGL((gemm_p8_mid_kernel<4, 0>), dim3(tiles, g.splitk), dim3(512), 4 * 256 * 128, s, g);
+    if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_mid_kernel<STAGES, 1>), dim3(tiles, g.splitk), dim3(512), STAGES * 256 * 128, s, g);
+    else hipLaunchKernelGGL((gemm_p8_mid_kernel<STAGES, 0>), dim3(tiles, g.splitk), dim3(512), STAGES * 256 * 128, s, g);
 }
 void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return;
     switch (g.force_cfg) {
-        case 28: launch_p8_mid(g, s); break;
+        case 28: launch_p8_mid<4>(g, s); break;
+        case 29: launch_p8_mid<5>(g, s); break;      // (experiment: the whole 160 KiB of LDS as a ring of 5 stages, four K tiles in flight)
         case 23: launch_p8_sm_cfg<64, 64, 8>(g, s); break;
         case 24: launch_p8_sm_cfg<64, 64, 5>(g, s); break;
         default: launch_p8_sm_cfg<64, 64, 4>(g, s); break;
@@ -1715,6 +1717,8 @@ void gemm_p8_prepare() {      // more than the default 64 KB of dynamic LDS (out
     for (const void* f : big5) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 576 * 128 + 4096);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_mid_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_mid_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_mid_kernel<5, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_mid_kernel<5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128);
     done[dev] = true;
 }
 // Production kernels: force_cfg 7 / 12 = gemm_p8_big_kernel with 256 x 256 / 320 x 256 tiles (persistent, one workgroup per CU),
