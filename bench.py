@@ -1,11 +1,13 @@
 #!/usr/bin/env python
 """Headline benchmark: motion frames/s of the audio->motion path at batch 32 x 10 s clips per GPU (BASELINE.json).
 
-One "step" = one pass of the whole hot path over one batch of 32 synthetic 10-second 16 kHz clips, measured as SURVEY.md
-section 8(d) defines the metric: H2D of the audio (20 MB from pinned host memory) -> wav2vec2 -> 5-scale AR decode with hipGraph
-replay -> VAE decode -> re-encode -> D2H of the FLAME codes (3.4 MB into pinned host memory).  Weight load and graph capture are
-outside (warmup).  ``--resident`` keeps the audio in HBM and leaves the codes there (the kernel-only number, reported as
-``resident`` in the default run as well).
+One "step" = one pass of the whole hot path over one batch of 32 synthetic 10-second 16 kHz clips: wav2vec2 -> 5-scale AR decode
+with hipGraph replay -> VAE decode -> re-encode.  Since round 4 the headline (``value``) is measured with the inputs RESIDENT in
+HBM when the timed region starts and the codes left in HBM, as the round's measurement contract asks; the same loop with the
+boundary a host caller sees - H2D of the audio (20 MB from pinned host memory) in front and D2H of the FLAME codes (3.4 MB into
+pinned host memory) behind every step, SURVEY.md section 8(d), the headline of rounds 2-3 - is timed right after it and reported
+as ``host_io`` (``--host-io`` makes it the headline again; then ``resident`` is the side figure).  Weight load and graph capture
+are outside (warmup).
 
 ``python bench.py --gpus N`` is ONE command for any N: for N > 1 the parent - before it touches the GPU - starts
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...`` as a child
@@ -33,7 +35,7 @@ GFLOP_PER_FRAME = 2.159          # algorithmic work with KV cache, BASELINE.md s
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
 SUSTAINED_F16_MFMA_TFLOPS = 1745.0   # measured: register-only v_mfma_f32_32x32x16_f16 loop whose operands change from MFMA to MFMA holds 1.67-1.70 GHz (profiles/r03_mfma_f16_peak.log)
-PMC_TRAFFIC_FILE = "profiles/r03_pmc_traffic.json"      # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
+PMC_TRAFFIC_FILE = "profiles/r04_pmc_traffic.json"      # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
 MODES = {
     # precision -> (dtype string, dominant kernel symbol prefix in the PMC file, description, peak TF/s of ALGORITHMIC flops, note)
     "f32": ("f32", "gemm_f32_kernel<128, 128, 2, 2, 16, 0, 0>",
@@ -99,7 +101,10 @@ def parse_args(argv=None):
     ap.add_argument("--branches", type=int, default=0, help="concurrent clip groups of the AR body (0 = auto)")
     ap.add_argument("--splitk", default="0,0", help="tuning: split-K tile threshold,target workgroups (0 = keep)")
     ap.add_argument("--synchronous", action="store_true", help="wait for every batch before the next one is enqueued (default: two batches in flight)")
-    ap.add_argument("--resident", action="store_true", help="audio already in HBM, codes left in HBM (no PCIe copies in the step)")
+    ap.add_argument("--resident", action="store_true", help="(the default since round 4; kept so that older command lines still parse)")
+    ap.add_argument("--host-io", action="store_true", help="headline step = H2D of the audio from pinned host memory + the path + D2H of the codes "
+                    "(what rounds 2-3 reported as `value`); default: inputs resident in HBM when the timed region starts, the PCIe-inclusive "
+                    "rate is reported beside it as `host_io`")
     ap.add_argument("--force-collective", action="store_true", help="N = 1: still create the RCCL process group and run the all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--io-probe", default="", choices=["", "h2d", "d2h"], help="(diagnosis) keep only the upload or only the download of the step's PCIe copies")
@@ -198,7 +203,7 @@ def main():
     host_audio = [clips[i] for i in mine]                                         # pinned host memory
     dev_audio = [a.to(dev) for a in host_audio]                                   # the same clips resident in HBM (--resident)
     host_outs = [torch.empty(B, frames_per_clip, cfg.motion_dim).pin_memory() for _ in range(2)]   # D2H targets of the local codes (one per batch in flight)
-    state = {"resident": args.resident, "pipelined": not args.synchronous, "k": 0, "last_host": 0}
+    state = {"resident": not args.host_io, "pipelined": not args.synchronous, "k": 0, "last_host": 0}
 
     def infer_fn(audios, styles):
         src = dev_audio if (state["resident"] or args.io_probe == "d2h") else audios   # host tensors: H2D happens inside inference_batch
@@ -384,14 +389,18 @@ def main():
         dts, _ = timed(n)
         state["pipelined"] = True
         result["synchronous"] = {"value": round(n * B * frames_per_clip / dts, 1), "ms_per_step": round(dts / n * 1e3, 2)}
-    if extras and not args.resident:
-        # the same steps with the audio resident and the codes left in HBM (what round 1 reported): the PCIe share of the step
-        state["resident"] = True
+    if extras:
+        # the same steps with the OTHER placement of the inputs: `host_io` = the boundary as a host caller sees it (H2D of the 20 MB of audio
+        # from pinned host memory -> the path -> D2H of the 3.4 MB of codes; the headline of rounds 2-3), `resident` = audio in HBM, codes left there
+        other = not state["resident"]
+        state["resident"] = other
         step(); torch.cuda.synchronize()
-        dtr, _ = timed(max(2, args.steps // 2))
-        state["resident"] = False
         n = max(2, args.steps // 2)
-        result["resident"] = {"value": round(n * B * frames_per_clip / dtr, 1), "ms_per_step": round(dtr / n * 1e3, 2)}
+        dtr, _ = timed(n)
+        state["resident"] = not other
+        result["resident" if other else "host_io"] = {"value": round(n * B * frames_per_clip / dtr, 1), "ms_per_step": round(dtr / n * 1e3, 2),
+                                                      "io": ("audio resident in HBM, codes left in HBM" if other else
+                                                             "H2D of the audio from pinned host memory and D2H of the codes to pinned host memory inside every step")}
     if extras and args.precision == "f16x3":
         # the same workload in the other GEMM mode (exact fp32 MFMA), outside the timed region: the f32 kernel is MFMA-bound and
         # sits much closer to its (6x lower) roofline, the f16x3 kernel is faster in absolute terms

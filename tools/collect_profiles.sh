@@ -11,10 +11,10 @@ python tools/summarize_profile.py stats $O/kt_f16x3 $O/f16x3_kernel_stats.csv > 
 python tools/summarize_profile.py shapes $O/kt_f16x3 $O/f16x3_launch_shapes.csv > /dev/null
 find $O/kt_f16x3 -name "*kernel_trace.csv" -delete
 echo "== kernel trace, one clip group: the AR/VAE body per scale step"
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_b32 -- python3 bench.py --steps 2 --warmup 2 --branches 1 --resident --no-cpu-baseline --no-alt-mode > $O/kt_b32.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_b32 -- python3 bench.py --steps 2 --warmup 2 --branches 1 --no-cpu-baseline --no-alt-mode > $O/kt_b32.log 2>&1
 python tools/summarize_profile.py levels $O/kt_b32 $O/body_levels_b32.csv > /dev/null
 find $O/kt_b32 -name "*kernel_trace.csv" -delete
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_b16 -- python3 bench.py --steps 2 --warmup 2 --batch 16 --branches 1 --resident --no-cpu-baseline --no-alt-mode > $O/kt_b16.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_b16 -- python3 bench.py --steps 2 --warmup 2 --batch 16 --branches 1 --no-cpu-baseline --no-alt-mode > $O/kt_b16.log 2>&1
 python tools/summarize_profile.py levels $O/kt_b16 $O/body_levels_b16.csv > /dev/null
 find $O/kt_b16 -name "*kernel_trace.csv" -delete
 echo "== roctx ranges (marker trace)"
