@@ -171,3 +171,47 @@ def test_bench_self_launch_relays_children_failure():
     assert proc.returncode != 0
     assert "torch.distributed.run" in proc.stderr and "--nproc-per-node=2" in proc.stderr and "127.0.0.1" in proc.stderr
     assert '"metric"' not in proc.stdout
+
+
+def _short_infer(audios, styles):
+    """An infer_fn that returns one frame less than the host formula says (a bug the gather must not hide)."""
+    return [o[:-1] for o in _fake_infer(audios, styles)]
+
+
+def _worker_mismatch(rank, world, port, n_clips, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    audios = [torch.full((16000 + 640 * i,), float(i + 1)) for i in range(n_clips)]
+    ok = False
+    try:
+        # run_sharded derives every clip's frame count from its sample count on the host; gather_clips slices the gathered buffer by those
+        # counts - if infer_fn returned something else, rows would be truncated or zero rows returned without this check (ADVICE r3)
+        run_sharded(_short_infer, audios, None, gather=True)
+    except AssertionError as e:
+        ok = "host-derived length" in str(e)
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_gather_rejects_lengths_that_differ_from_the_host_formula():
+    _run(5, _worker_mismatch)
+
+
+def test_as_rank_walks_the_shards_of_a_larger_job_locally():
+    """run_sharded(as_rank=(r, W)): the shard rank r of a W-rank job computes, through the same local path, without a process group (what
+    tests/test_configs_gpu.py::test_config3_workload_on_one_gpu does with the 8 x 32 clips of BASELINE configs[3] on one GPU)."""
+    audios = [torch.full((16000 + 640 * i,), float(i + 1)) for i in range(11)]
+    want = _fake_infer(audios, None)
+    seen = []
+    for r in range(4):
+        mine = shard_range(11, r, 4)
+        outs = run_sharded(_fake_infer, audios, None, gather=False, as_rank=(r, 4))
+        assert len(outs) == len(mine)
+        for k, i in enumerate(mine):
+            assert torch.equal(outs[k], want[i])
+        seen += list(mine)
+    assert seen == list(range(11))
+    import pytest
+    with pytest.raises(AssertionError):
+        run_sharded(_fake_infer, audios, None, gather=True, as_rank=(0, 4))

@@ -1,7 +1,7 @@
 # Collects everything kept under profiles/ for a round: run on the GPU box as
 #   gpurun -- 'bash tools/collect_profiles.sh r02'   (outputs under gpurun_out/<round>/, then copied into profiles/ by hand)
 set -e
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 rm -rf $O && mkdir -p $O
@@ -41,6 +41,11 @@ echo "# the same with the epilogues the model uses: P8 result + GELU (q|k|v: P8 
 GEMM_ACT=0x101 GEMM_GRAPH=0 GEMM_VARIANTS="13:1,7:1,12:1,8:1,99:1" GEMM_ONLY="w2v qkv,w2v ff1" timeout -k 10 300 python tools/gemm_f16s_bench.py 2>&1 | grep -v amdgpu.ids >> $O/gemm_f16s_bench.log
 GEMM_ACT=0x200 GEMM_GRAPH=0 GEMM_VARIANTS="7:1,12:1,8:1,99:1" GEMM_ONLY="w2v out,w2v ff2" timeout -k 10 300 python tools/gemm_f16s_bench.py 2>&1 | grep -v amdgpu.ids >> $O/gemm_f16s_bench.log
 timeout -k 10 100 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > $O/attn_bench.log
+echo "# the encoder shape without the persistent ping-pong kernel (ARTALK_ATTN_PP=0: one head per workgroup, keys staged once)" >> $O/attn_bench.log
+ARTALK_ATTN_PP=0 ATTN_ONLY=w2v timeout -k 10 100 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids >> $O/attn_bench.log
+echo "== matrix-pipe duty per instantiation of the dominant kernel (PMC passes of the real step)"
+bash tools/pmc_mfma_bench.sh $R > /dev/null 2>&1 || echo "mfma pmc failed"
+cat $O/mfma_util_per_instantiation.log
 echo "== P8 headroom"
 timeout -k 10 200 python tools/p8_headroom.py $O/p8_headroom.json 2>&1 | grep -v amdgpu.ids | tail -14
 ls $O
