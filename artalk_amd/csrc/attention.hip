@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
 // t = w, w+4, ...): K and V fragments go straight from global memory into MFMA operand registers (their lane maps are
 // row-contiguous: 64-byte pieces of a key row for K, whole 256-byte rows for V), the next tile's loads are issued before
 // the current tile's MFMAs, no LDS and no barrier in the loop; the four partial (m, l, O) are merged through LDS at the end.
-template <int HD>
+template <int HD, bool SLABS = false>      // SLABS: AttnArgs::slabs is set (its own instantiation: the slab path costs 27 registers, and the
+                                           // 25- / 50-query steps, which never take it, need three workgroups per CU)
 __global__ __launch_bounds__(256, 2) void attention_short_kernel(const AttnArgs a) {      // (2 blocks per CU: at most 256 registers per wave, which is what makes hipcc keep the MFMA accumulators in VGPRs - with the full 512 it put them in AGPRs and moved them out and back around the softmax and the rescale, 123 v_accvgpr moves and 66 hazard nops per tile pair)
     static_assert(HD == 64, "head dim");
     constexpr int NC = 4, NDT = 4;
@@ -222,13 +223,36 @@ __global__ __launch_bounds__(256, 2) void attention_short_kernel(const AttnArgs 
     const int qi = q0 + r;
     const bool qvalid = qi < a.Lq;
 
+    // Lq <= 16 with split-K slabs (AttnArgs::slabs): the q | k | v rows of the NEW tokens (the queries, and the last Lq keys) are not in
+    // the cache yet - a lane that needs four of their values sums them from the slabs itself, in splitk_reduce_kernel's order (0 + slab 0
+    // + slab 1 + ... + bias), straight into the fragment register the cache row would have been loaded into: no reduce launch, no trip
+    // through memory.  The lanes that own a new K / V row also write it to the cache (raw, before the L2 norm) for the later scale steps.
+    const int E = a.H * HD;
+    const int new0 = a.Lk - a.Lq;                                  // first new key row
+    auto from_slabs = [&](int t, int col) {                        // row t (0 .. Lq-1) of this clip, 4 columns from `col` of q | k | v
+        // every load of a batch of 8 slabs is issued before the first add (the slabs were written a moment ago by workgroups on other XCDs:
+        // each load is an L2 miss, and a run-time loop pays those latencies one after the other); the adds keep the slab order
+        const float* p = a.slabs + ((long)b * a.Lq + t) * a.slab_ld + col;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 bias = a.slab_bias ? *reinterpret_cast<const f32x4*>(a.slab_bias + col) : v;
+        for (int y0 = 0; y0 < a.n_slabs; y0 += 8) {
+            f32x4 tt[8];
+#pragma unroll
+            for (int y = 0; y < 8; ++y) tt[y] = *reinterpret_cast<const f32x4*>(p + (long)min(y0 + y, a.n_slabs - 1) * a.slab_stride);
+#pragma unroll
+            for (int y = 0; y < 8; ++y) if (y0 + y < a.n_slabs) v += tt[y];
+        }
+        if (a.slab_bias) v += bias;
+        return v;
+    };
     f32x4 qf[NC];
     {
         const float* qp = a.Q + (long)b * a.q_bstride + (long)qi * a.ldq + h * HD;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            qf[c] = qvalid ? *reinterpret_cast<const f32x4*>(qp + 4 * (g + 4 * c)) : z;
+            if (SLABS) qf[c] = qvalid ? from_slabs(qi, h * HD + 4 * (g + 4 * c)) : z;
+            else qf[c] = qvalid ? *reinterpret_cast<const f32x4*>(qp + 4 * (g + 4 * c)) : z;
         }
         if (a.l2norm) {
             float ss = 0.f;
@@ -260,13 +284,27 @@ __global__ __launch_bounds__(256, 2) void attention_short_kernel(const AttnArgs 
     f32x4 kf[2][NC], vf[2][4];
     auto load_tile = [&](int t, int slot) {
         const int kr = min(t * 16 + r, a.Lk - 1);
-        const float* kp = Kb + (long)kr * a.ldk;
+        float* kp = const_cast<float*>(Kb) + (long)kr * a.ldk;
+        if (SLABS && kr >= new0) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) kf[slot][c] = *reinterpret_cast<const f32x4*>(kp + 4 * (g + 4 * c));
+            for (int c = 0; c < NC; ++c) {
+                kf[slot][c] = from_slabs(kr - new0, E + h * HD + 4 * (g + 4 * c));
+                if (t * 16 + r < a.Lk) *reinterpret_cast<f32x4*>(kp + 4 * (g + 4 * c)) = kf[slot][c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kf[slot][c] = *reinterpret_cast<const f32x4*>(kp + 4 * (g + 4 * c));
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int vr = min(t * 16 + 4 * g + j, a.Lk - 1);
-            vf[slot][j] = *reinterpret_cast<const f32x4*>(Vb + (long)vr * a.ldv + NDT * r);
+            float* vp = const_cast<float*>(Vb) + (long)vr * a.ldv + NDT * r;
+            if (SLABS && vr >= new0) {
+                vf[slot][j] = from_slabs(vr - new0, 2 * E + h * HD + NDT * r);
+                if (t * 16 + 4 * g + j < a.Lk) *reinterpret_cast<f32x4*>(vp) = vf[slot][j];
+            } else {
+                vf[slot][j] = *reinterpret_cast<const f32x4*>(vp);
+            }
         }
     };
 
@@ -1331,7 +1369,10 @@ void attention_prepare() {      // more than the default 64 KB of dynamic LDS fo
 void launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.Lq <= 0) return;
     if (a.HD == 64 && a.split_q == 0 && a.Lq <= 64 && a.Lk >= 64 && !a.qkv_p8) {      // AR scale steps 0-3: key-split kernel
-        hipLaunchKernelGGL(attention_short_kernel<64>, dim3(((a.H * a.B + 7) / 8) * 8 * ((a.Lq + 15) / 16)), dim3(256), 0, s, a);
+        const dim3 grid(((a.H * a.B + 7) / 8) * 8 * ((a.Lq + 15) / 16));
+        if (a.slabs && a.Lq <= 16) hipLaunchKernelGGL((attention_short_kernel<64, true>), grid, dim3(256), 0, s, a);
+        else if (a.slabs) abort();      // (slabs are only handed over for one query tile per head: engine.hip run_chunk_body)
+        else hipLaunchKernelGGL((attention_short_kernel<64, false>), grid, dim3(256), 0, s, a);
         return;
     }
     dim3 grid((a.Lq + 63) / 64, a.H, a.B), block(256);

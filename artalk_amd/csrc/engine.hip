@@ -160,6 +160,13 @@ struct artalk_model {
     // result traffic and its hold on the CUs land on exactly the launches whose time is memory latency).  Off by default
     // (ARTALK_ADA_OVERLAP=1 switches it on for an A/B run; the second table is only allocated then).
     bool ada_overlap = false; int ada_cus = 192, cus_override = 0;
+    // The split-K reduce of the 1- / 5-token q|k|v GEMMs inside the short-query attention kernel (run_chunk_body): 12 launches fewer per
+    // scale step (113 -> 101), bit-identical (tests/test_edge_cases_gpu.py::test_fused_qkv_reduce_is_bit_identical) - and NOT faster: same
+    // box, alternating runs, body time 31.33 / 31.51 / 31.33 ms fused against 31.00 / 31.18 / 31.12 ms with the separate reduce pass
+    // (round 4).  The attention launch grows by what the reduce launch took: inside a graph a 4.8 us kernel costs less than its
+    // duration (the front end has the next dispatch ready), while the slab loads now sit on the attention kernel's own critical path.
+    // Off by default (ARTALK_FUSE_QKV_REDUCE=1 for an A/B run).
+    bool fuse_qkv_reduce = false;
     hipStream_t ada_stream = nullptr;
     hipEvent_t ada_done[2] = {nullptr, nullptr}, body_done[2] = {nullptr, nullptr}, ada_pre = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
@@ -429,7 +436,9 @@ void audit(artalk_model* m, const std::string& site, const float* buf, int rows,
     launch_absmax(buf, rows, cols & ~7, ld, is_p8 ? 1 : 0, m->audit_vals + idx, s, junk_period, junk_from);
 }
 
-bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse_ln = nullptr) {
+// defer_reduce: the caller's next kernel sums the split-K slabs itself (the short-query attention kernel does, for the q|k|v rows of
+// its own head): if this GEMM is split, its reduce pass is NOT launched and *defer_reduce receives the slab count (else 0).
+bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse_ln = nullptr, int* defer_reduce = nullptr) {
     GemmArgs g = g0;
     g.graph_tag = m->in_body ? 1 : 0;
     g.cus = m->cus_override > 0 ? (m->n_cus > 0 ? std::min(m->cus_override, m->n_cus) : m->cus_override) : m->n_cus;
@@ -503,8 +512,10 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
     else if (split) launch_gemm_f16s(g, s);
     else launch_gemm(g, s);
     bool fused = false;
+    if (defer_reduce) *defer_reduce = 0;
     if (g.splitk > 1) {
         if (fuse_ln && splitk_reduce_ln_eligible(g, *fuse_ln)) { launch_splitk_reduce_ln(g, *fuse_ln, s); fused = true; }
+        else if (defer_reduce && !c2) *defer_reduce = g.splitk;
         else launch_splitk_reduce(g, s);
     }
     if (c2 && !c2_fused) launch_pack_split(g.C, reinterpret_cast<unsigned int*>(c2), (long)g.M * g.N, false, s, g.status);
@@ -820,8 +831,15 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s, int n_reencode = -1) 
             GemmArgs q;
             q.A = w.xmod; q.lda = kE; q.W = L.qkv_w; q.ldw = kE; q.bias = L.qkv_b; q.C = cache; q.ldc = 3 * kE;
             q.cmap = rowmap(pn, 2 * kNTok, kNTok + off); q.M = M; q.N = 3 * kE; q.K = kE; q.a_packed = p8;
-            gemm(m, q, s);
+            // 1- and 5-token steps: a split q|k|v GEMM leaves its slabs to the attention kernel, whose workgroup (clip, head) sums the
+            // rows of its own head (same order: slabs ascending, then the bias), writes them to the KV cache and goes on - one launch
+            // less per block (ARTALK_FUSE_QKV_REDUCE=0: the separate reduce pass; a test compares both arms bit for bit)
+            int qkv_slabs = 0;
+            gemm(m, q, s, nullptr, (m->fuse_qkv_reduce && pn <= 16) ? &qkv_slabs : nullptr);
             AttnArgs a;
+            if (qkv_slabs > 0) {
+                a.slabs = w.splitk; a.n_slabs = qkv_slabs; a.slab_stride = (long)M * 3 * kE; a.slab_ld = 3 * kE; a.slab_bias = L.qkv_b;
+            }
             a.Q = cache + (long)(kNTok + off) * 3 * kE; a.K = cache + kE; a.V = cache + 2 * kE;
             a.ldq = a.ldk = a.ldv = 3 * kE; a.q_bstride = a.k_bstride = a.v_bstride = (long)2 * kNTok * 3 * kE;
             a.O = w.attn_out; a.ldo = kE; a.o_bstride = (long)pn * kE;
@@ -1095,6 +1113,7 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
     m->cfg = c; m->device = device_id;
     if (const char* e = getenv("ARTALK_ADA_OVERLAP")) m->ada_overlap = atoi(e) != 0;      // A/B switch: 0 = the table GEMM in line, in front of every body
     if (const char* e = getenv("ARTALK_ADA_CUS")) m->ada_cus = std::max(8, atoi(e));
+    if (const char* e = getenv("ARTALK_FUSE_QKV_REDUCE")) m->fuse_qkv_reduce = atoi(e) != 0;
     // conv stack geometry: T_l valid frames; row stride S_l per chunk with S_l = 2*S_{l+1} so that one GEMM covers all chunks
     int T = kSamplesPerChunk;
     for (int i = 0; i < c.w2v_n_conv; ++i) { T = (T - c.w2v_conv_kernel[i]) / c.w2v_conv_stride[i] + 1; m->conv_T[i] = T; }

@@ -113,6 +113,10 @@ struct AttnArgs {
     int qkv_p8 = 0;                                  // 1 (with split16, no l2norm): Q, K, V rows are in the P8 split format (written so by the qkv GEMM)
     int* status = nullptr;                           // out_p8: range guard (see GemmArgs::status)
     int cus = 0;                                     // compute units of the model's partition (0 = the whole device): grid of the persistent kernel
+    // short-query kernel, Lq <= 16: the q | k | v rows of the NEW tokens (the last Lq keys) are still split-K slabs [n_slabs][B * Lq][slab_ld]
+    // (row b * Lq + t; columns q | k | v x heads x 64): the workgroup sums its head's rows (slabs ascending, then slab_bias), writes them to
+    // Q / K / V and reads them back from there
+    const float* slabs = nullptr; int n_slabs = 0; long slab_stride = 0; int slab_ld = 0; const float* slab_bias = nullptr;
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 void attention_prepare();      // one-time kernel attributes (call once per process before the first captured launch)

@@ -262,3 +262,40 @@ def test_cu_partition_gives_the_same_results():
     again = [o.cpu() for o in m.inference_batch(audios)]
     for a, b in zip(again, want):
         assert torch.equal(a, b)
+
+
+_FUSE_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from conftest import get_gpu_model
+from artalk_amd.synth import synth_audio
+m = get_gpu_model("tiny")
+audios = [torch.from_numpy(synth_audio(300 + i, s)) for i, s in enumerate((10.0, 6.3, 4.0, 9.1, 2.2))]
+res = {}
+for prec in ("f16x3", "f32"):
+    m.set_precision(prec)
+    outs = m.inference_batch(audios, None, return_aux=True)
+    res[prec + "_out"] = np.concatenate([o.cpu().numpy() for o in outs])
+    res[prec + "_bits"] = np.concatenate([b.cpu().numpy().reshape(-1) for b in m.last_aux["bits"]])
+    one = m.inference_batch(audios[:1], None)[0]
+    res[prec + "_one"] = one.cpu().numpy()
+np.savez(sys.argv[2], **res)
+"""
+
+
+def test_fused_qkv_reduce_is_bit_identical(tmp_path):
+    """With ARTALK_FUSE_QKV_REDUCE=1 the 1- / 5-token scale steps leave the split-K slabs of their q|k|v GEMM to the short-query
+    attention kernel, whose lanes sum the rows they need straight into their fragment registers (engine.hip run_chunk_body,
+    attention.hip AttnArgs::slabs): one launch less per block (measured: not faster, so it is off by default - DESIGN.md section 3).
+    Same order of additions as the separate reduce pass, so every code and bit must be IDENTICAL between the arms (switch read at
+    model creation: each arm runs in a child process), for a ragged batch of 5 and for batch 1, in both precisions."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    arms = []
+    for fuse in ("1", "0"):
+        f = str(tmp_path / f"fuse{fuse}.npz")
+        subprocess.run([sys.executable, "-c", _FUSE_CHILD, root, f], check=True, env=dict(os.environ, ARTALK_FUSE_QKV_REDUCE=fuse), timeout=600)
+        arms.append(np.load(f))
+    for k in arms[0].files:
+        assert np.isfinite(arms[0][k]).all() or arms[0][k].dtype == np.uint8
+        assert np.array_equal(arms[0][k], arms[1][k]), k
