@@ -122,11 +122,14 @@ def pytest_sessionfinish(session, exitstatus):
     if not ROUNDING_OBSERVED:
         return
     import json
-    d = os.path.join(REPO, "gpurun_out")
-    os.makedirs(d, exist_ok=True)
-    with open(os.path.join(d, "rounding_level_observed.json"), "w") as f:
-        json.dump({"clips": {k: v for k, v in sorted(ROUNDING_OBSERVED.items()) if v["stages"]},
-                   "checked": len(ROUNDING_OBSERVED)}, f, indent=1)
+    try:      # (a record for the builder, never a reason for the session to fail: the checkout may be read-only)
+        d = os.path.join(REPO, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "rounding_level_observed.json"), "w") as f:
+            json.dump({"clips": {k: v for k, v in sorted(ROUNDING_OBSERVED.items()) if v["stages"]},
+                       "checked": len(ROUNDING_OBSERVED)}, f, indent=1)
+    except OSError:
+        pass
 
 
 _LEVEL_OF = None
