@@ -76,3 +76,22 @@ def test_intermediates_against_reference(case, precision):
     text = f"{case} [{precision}] intermediates vs the reference (relative to each field's scale):\n  " + "\n  ".join(report)
     print(text)
     assert worst < TOL_REL, text
+
+
+def test_taps_of_a_ragged_batch_equal_the_single_runs():
+    """The tap slots are indexed by (chunk index, clip position in the call's sorted order): a ragged batch of three clips must give
+    every clip the intermediates of its own batch-1 run (to rounding: tile shapes depend on the row count), in the caller's order."""
+    from artalk_amd.synth import synth_audio
+    m = get_gpu_model("tiny")
+    m.set_precision("f32")
+    audios = [torch.from_numpy(synth_audio(700 + i, s)) for i, s in enumerate((4.0, 10.0, 6.3))]      # 1, 3, 2 chunks: sorted order 1, 2, 0
+    m.inference_batch(audios, None, return_aux=True, taps=True)
+    batch = [{k: v.cpu().numpy() for k, v in t.items()} for t in m.last_aux["taps"]]
+    for i, a in enumerate(audios):
+        m.inference_batch([a], None, return_aux=True, taps=True)
+        one = {k: v.cpu().numpy() for k, v in m.last_aux["taps"][0].items()}
+        for f in FIELDS:
+            assert batch[i][f].shape == one[f].shape == (m.n_chunks(a.shape[0]),) + one[f].shape[1:]
+            scale = np.abs(one[f]).max()
+            err = np.abs(batch[i][f] - one[f]).max() / scale
+            assert err < 1e-5, f"clip {i} field {f}: {err:.2e}"
