@@ -283,18 +283,21 @@ np.savez(sys.argv[2], **res)
 """
 
 
-def test_fused_qkv_reduce_is_bit_identical(tmp_path):
+@pytest.mark.parametrize("switch", ["ARTALK_FUSE_QKV_REDUCE", "ARTALK_ADA_OVERLAP"])
+def test_fused_qkv_reduce_is_bit_identical(tmp_path, switch):
     """With ARTALK_FUSE_QKV_REDUCE=1 the 1- / 5-token scale steps leave the split-K slabs of their q|k|v GEMM to the short-query
     attention kernel, whose lanes sum the rows they need straight into their fragment registers (engine.hip run_chunk_body,
     attention.hip AttnArgs::slabs): one launch less per block (measured: not faster, so it is off by default - DESIGN.md section 3).
     Same order of additions as the separate reduce pass, so every code and bit must be IDENTICAL between the arms (switch read at
-    model creation: each arm runs in a child process), for a ragged batch of 5 and for batch 1, in both precisions."""
+    model creation: each arm runs in a child process), for a ragged batch of 5 and for batch 1, in both precisions.
+    ARTALK_ADA_OVERLAP=1 (the AdaLN table of chunk index j + 1 on a stream of its own beside body j, two tables, graphs keyed by table
+    parity; also measured and off by default) is held to the same bar: same kernels on other streams, identical results."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     arms = []
     for fuse in ("1", "0"):
         f = str(tmp_path / f"fuse{fuse}.npz")
-        subprocess.run([sys.executable, "-c", _FUSE_CHILD, root, f], check=True, env=dict(os.environ, ARTALK_FUSE_QKV_REDUCE=fuse), timeout=600)
+        subprocess.run([sys.executable, "-c", _FUSE_CHILD, root, f], check=True, env=dict(os.environ, **{switch: fuse}), timeout=600)
         arms.append(np.load(f))
     for k in arms[0].files:
         assert np.isfinite(arms[0][k]).all() or arms[0][k].dtype == np.uint8
