@@ -1,4 +1,4 @@
-"""The bench line committed for this round (profiles/r03_bench_line.json, written by `python bench.py` on an MI355X) keeps the
+"""The bench line committed for the latest round (profiles/r0N_bench_line.json, written by `python bench.py` on an MI355X) keeps the
 contract the driver reads: the required keys, a roofline object whose fraction is achieved / peak, a cpu_baseline object, and a value
 that is the whole-job rate of the step time next to it.  No GPU needed: the file is data."""
 import glob
