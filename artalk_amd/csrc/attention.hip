@@ -1042,9 +1042,14 @@ __global__ __launch_bounds__(kPPWaves * 64) void attention_f16_pp_kernel(const A
             }
         };
 
+        // The LDS-DMA of a buffer is ordered before the other waves' reads of it by the issuing wave's OWN vmcnt(0) in front of the
+        // barrier - spelled out: hipcc happened to place one at the first barrier (from the fence) and none at the second
+        // (buffer A of the next head was complete only through a data dependence on later global loads); gfx950 inserts no wait by itself.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                 // A of this head has landed for every wave (vmcnt(0) + barrier); everyone is done with B of the previous head
         issue_buffer(item, bufB, kPPRowsB, kPPRowsA);
         if (wave_active) phase(bufA, std::integral_constant<int, kPPRowsA>{}, 0, 0, min(a.Lk, kPPRowsA));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                 // B has landed; everyone is done with A
         if (next < n_items) {
             issue_buffer(next, bufA, kPPRowsA, 0);
@@ -1385,8 +1390,12 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         // (14.1 -> 11.9 us); the encoder's 1536 pairs run the same either way (109 us: bound by the softmax arithmetic, not by staging)
         // ARTALK_ATTN_PP [1]: the persistent ping-pong kernel where every CU gets several heads (the encoder); 0 = the one-head-per-workgroup kernel
         static const int pp = getenv("ARTALK_ATTN_PP") ? atoi(getenv("ARTALK_ATTN_PP")) : 1;
-        static int n_cu = 0;
-        if (!n_cu && (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || n_cu <= 0)) n_cu = 256;
+        static int n_cu_dev[64] = {};      // per device: the CURRENT one (a model may live on any GPU of the node)
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64) dev = 0;
+        int& n_cu = n_cu_dev[dev];
+        if (!n_cu && (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)) n_cu = 256;
         const int cus = a.cus > 0 ? (a.cus < n_cu ? a.cus : n_cu) : n_cu;
         if (pp && wide != 2 && a.split_q <= 0 && a.Lk > kPPRowsA && a.Lk <= kPPRowsA + kPPRowsB && (long)a.B * a.H >= 2L * cus) {
             hipLaunchKernelGGL((attention_f16_pp_kernel<1>), dim3(cus), dim3(kPPWaves * 64), (size_t)4 * (kPPRowsA + kPPRowsB) * 160, s, a);

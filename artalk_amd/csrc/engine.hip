@@ -75,7 +75,7 @@ struct Workspace {
     float *h0 = nullptr, *h1 = nullptr, *xln = nullptr, *qkv = nullptr, *att = nullptr, *ffn = nullptr;
     float* silu_cond = nullptr;     // [maxC*181, 1024]
     // AR
-    float *ada = nullptr, *ada2 = nullptr, *style_cond = nullptr, *prev_in = nullptr, *prev_in_p8 = nullptr, *cache = nullptr;
+    float *ada = nullptr, *style_cond = nullptr, *prev_in = nullptr, *prev_in_p8 = nullptr, *cache = nullptr;
     float *x = nullptr, *xmod = nullptr, *attn_out = nullptr, *ffn_h = nullptr, *logits = nullptr;
     float *fhat = nullptr, *nextfeat = nullptr;
     float* splitk = nullptr; int64_t splitk_floats = 0;   // partial sums of split-K GEMMs
@@ -152,14 +152,6 @@ struct artalk_model {
     std::vector<std::pair<int, size_t>> marks;          // (bucket of the interval ending here, event index), caller's stream
     hipStream_t prof_stream = nullptr;
     hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};   // extra branches of the AR body (run_chunk_body_graphs)
-    // Overlapped AdaLN tables (artalk_infer): the table of chunk index j + 1 does not depend on the AR state, so its GEMM runs on a
-    // stream of its own, on a REDUCED grid (ada_cus of the CUs: a persistent workgroup holds its CU for the whole launch, the free CUs
-    // are what the body's small kernels run on), beside the latency-bound first scale steps of body j; two tables (Workspace::ada / ada2).
-    // MEASURED, NOT A GAIN (round 4, same box, profiles/r04_ada_overlap_sweep.log): in line 5.0 + 31.7 ms (tables + bodies), overlapped on
-    // 128 / 192 / 256 CUs 1.7 + 37.0 / 36.2 / 35.1 ms - the bodies slow down by what the table GEMM takes (its 3 TB/s of operand and
-    // result traffic and its hold on the CUs land on exactly the launches whose time is memory latency).  Off by default
-    // (ARTALK_ADA_OVERLAP=1 switches it on for an A/B run; the second table is only allocated then).
-    bool ada_overlap = false; int ada_cus = 192, cus_override = 0;
     // The split-K reduce of the 1- / 5-token q|k|v GEMMs inside the short-query attention kernel (run_chunk_body): 12 launches fewer per
     // scale step (113 -> 101), bit-identical (tests/test_edge_cases_gpu.py::test_fused_qkv_reduce_is_bit_identical) - and NOT faster: same
     // box, alternating runs, body time 31.33 / 31.51 / 31.33 ms fused against 31.00 / 31.18 / 31.12 ms with the separate reduce pass
@@ -167,13 +159,13 @@ struct artalk_model {
     // duration (the front end has the next dispatch ready), while the slab loads now sit on the attention kernel's own critical path.
     // Off by default (ARTALK_FUSE_QKV_REDUCE=1 for an A/B run).
     bool fuse_qkv_reduce = false;
-    hipStream_t ada_stream = nullptr;
-    hipEvent_t ada_done[2] = {nullptr, nullptr}, body_done[2] = {nullptr, nullptr}, ada_pre = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
     int branches = 0;                 // 0 = automatic (2 for B >= 8), else forced 1/2/4
     hipStream_t own_stream = nullptr;   // used when the caller passes stream == NULL (graph capture needs a real stream)
-    // graphs: one per (active batch size, clip group, precision)
-    std::map<long long, hipGraphExec_t> graphs;
+    // graphs: one per (active batch size, clip group, precision, re-encoded clips), LRU-bounded (run_chunk_body_graphs)
+    struct GraphEntry { hipGraphExec_t exec = nullptr; long long last_use = 0; };
+    std::map<long long, GraphEntry> graphs;
+    long long graph_clock = 0, graph_captures = 0;
     // Pinned host staging for the small per-call tables (chunk offsets, style flags): a ring of slots, each guarded by an event
     // recorded after its H2D copies, so artalk_infer never has to wait for its own copies (it blocks only if kStageSlots calls
     // are still in flight).  h_status receives the device status word at the end of every call (async), status_ev marks it.
@@ -441,7 +433,7 @@ void audit(artalk_model* m, const std::string& site, const float* buf, int rows,
 bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse_ln = nullptr, int* defer_reduce = nullptr) {
     GemmArgs g = g0;
     g.graph_tag = m->in_body ? 1 : 0;
-    g.cus = m->cus_override > 0 ? (m->n_cus > 0 ? std::min(m->cus_override, m->n_cus) : m->cus_override) : m->n_cus;
+    g.cus = m->n_cus;
     g.status = m->precision == 1 ? (m->view ? m->view->status : m->ws.status) : nullptr;     // P8 range guard at the producers
     bool split = false;
     if (m->precision == 1 && !g.exact) {
@@ -703,7 +695,7 @@ void run_vae_stack(artalk_model* m, const VAESide& S, int B, int T, int split, h
         a.B = B; a.H = c.vae_heads; a.HD = H / c.vae_heads; a.Lq = T; a.Lk = T;
         a.scale = 1.0f / std::sqrt((float)H);      // hidden_dim**-0.5, NOT head_dim (bitwise_vae.py:198)
         audit(m, an + ".qkv", w.vqkv, M, 3 * H, 3 * H, p8, s);
-        a.split_q = split; a.split_k = split; a.out_p8 = p8; a.split16 = p8; a.status = p8 ? w.status : nullptr;
+        a.split_q = split; a.split_k = split; a.out_p8 = p8; a.split16 = p8; a.status = p8 ? w.status : nullptr; a.cus = m->n_cus;
         launch_attention(a, s);
         audit(m, an + ".attn_out", w.vatt, M, H, H, p8, s);
         // the MLP reads the residual stream itself (no LayerNorm in front of it, bitwise_vae.py:139-145).  In f16x3 mode the
@@ -749,7 +741,14 @@ int run_init_history(artalk_model* m, int B, hipStream_t s) {
         HIPCHK(m, hipMemcpyAsync(ih.bits, w.hist_bits, nb, hipMemcpyDeviceToDevice, s));
         HIPCHK(m, hipMemcpyAsync(ih.fdec, w.prev_fdec, nf, hipMemcpyDeviceToDevice, s));
         HIPCHK(m, hipMemcpyAsync(ih.msfeat, w.msfeat, nm, hipMemcpyDeviceToDevice, s));
-        ih.valid = true;
+        // The cache is complete before this call returns to its caller's enqueue loop: a later call on ANOTHER stream reads it with no
+        // ordering against this fill otherwise.  Once per model and mode, beside the hipMalloc above.  A fill that raised a
+        // health flag (the range guard of the P8 format, a non-finite value) is NOT kept: every later call would reuse the damaged
+        // history with a clean status word; it is recomputed - and flagged again - by the next call instead.
+        int flags[4] = {0, 0, 0, 0};
+        HIPCHK(m, hipMemcpyAsync(flags, w.status, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(m, hipStreamSynchronize(s));
+        ih.valid = flags[0] == 0;
     }
     launch_broadcast16(ih.bits, w.hist_bits, nb, B, s);
     launch_broadcast16(ih.fdec, w.prev_fdec, nf, B, s);
@@ -892,11 +891,10 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s, int n_reencode = -1) 
 
 // A view of the workspace for clips [b0, ...): every per-clip buffer pointer advanced by b0 clips (compact step buffers get a
 // fixed 100-row region per clip so the two halves never overlap), its own split-K scratch.
-Workspace clip_view(const artalk_model* m, int b0, int branch, int parity = 0) {
+Workspace clip_view(const artalk_model* m, int b0, int branch) {
     const artalk_config& c = m->cfg;
     Workspace v = m->ws;
     const long b = b0;
-    if (parity && v.ada2) v.ada = v.ada2;       // (the table this chunk index reads: artalk_infer's overlapped AdaLN schedule)
     v.ada += b * kNTok * m->ada_n; v.style_cond += b * kE; v.prev_in += b * kNTok * kE; v.prev_in_p8 += b * kNTok * kE;
     v.cache += b * 2 * kNTok * 3 * kE;
     v.x += b * 100 * kE; v.xmod += b * 100 * kE; v.attn_out += b * 100 * kE; v.ffn_h += b * 100 * 4 * kE;
@@ -950,40 +948,67 @@ int body_branches(const artalk_model* m, int B) {
     const int want = m->branches > 0 ? m->branches : (B >= 8 ? 2 : 1);
     return B >= 2 * want ? want : (B >= 8 ? 2 : 1);
 }
-int run_chunk_body_graphs(artalk_model* m, int B, hipStream_t s, int parity = 0, int n_next = -1) {
+// Graph cache: one hipGraphExec per (active clips, clip group, precision, re-encoded clips of the group).  The key space is bounded
+// (ADVICE r4): the re-encode count of a group is rounded UP to a multiple of 8 (re-encoding a clip without a next chunk is what the
+// reference does anyway, app/models.py:111-114; its history is never read), so a group contributes at most 1 + size / 8 keys per
+// active-batch size instead of one per (B_j, B_j+1) pair; and the cache holds at most kMaxGraphs executables, least recently used
+// evicted (a serving loop with ever-changing ragged batches re-captures instead of growing without bound).
+constexpr size_t kMaxGraphs = 96;
+int evict_graphs(artalk_model* m, const long long* keep, int n_keep) {
+    while (m->graphs.size() >= kMaxGraphs) {
+        auto victim = m->graphs.end();
+        for (auto it = m->graphs.begin(); it != m->graphs.end(); ++it) {
+            bool pinned = false;
+            for (int i = 0; i < n_keep; ++i) pinned |= it->first == keep[i];
+            if (!pinned && (victim == m->graphs.end() || it->second.last_use < victim->second.last_use)) victim = it;
+        }
+        if (victim == m->graphs.end()) break;
+        HIPCHK(m, hipDeviceSynchronize());      // the victim may still be running on a side stream of an earlier call
+        (void)hipGraphExecDestroy(victim->second.exec);
+        m->graphs.erase(victim);
+    }
+    return ARTALK_OK;
+}
+int run_chunk_body_graphs(artalk_model* m, int B, hipStream_t s, int n_next = -1) {
     if (n_next < 0 || n_next > B) n_next = B;
     if (B > 4095) { run_chunk_body(m, B, s, n_next); return ARTALK_OK; }      // (graph keys hold 12 bits of clip counts)
     const int NS = body_branches(m, B);
     if (NS > 1) { if (int rc = ensure_side_streams(m, NS - 1)) return rc; }
     Workspace views[4];
-    int b0[5];
+    int b0[5], nres[4];
     for (int h = 0; h <= NS; ++h) b0[h] = (int)((long)B * h / NS);
     hipStream_t st[4] = {s, m->side_stream[0], m->side_stream[1], m->side_stream[2]};
     long long keys[4];
     for (int h = 0; h < NS; ++h) {
-        views[h] = clip_view(m, b0[h], h, parity);
-        const int nre = std::max(0, std::min(n_next - b0[h], b0[h + 1] - b0[h]));      // clips of this group that have a next chunk
-        const long long key = ((long long)((((B * 8 + NS) * 4 + h) * 2 + m->precision) * 2 + parity)) * 4096 + nre;
-        keys[h] = key;
-        if (m->graphs.find(key) != m->graphs.end()) continue;
+        const int gsz = b0[h + 1] - b0[h];
+        const int need = std::max(0, std::min(n_next - b0[h], gsz));      // clips of this group that have a next chunk
+        nres[h] = std::min(gsz, (need + 7) / 8 * 8);
+        keys[h] = ((long long)(((B * 8 + NS) * 4 + h) * 2 + m->precision)) * 4096 + nres[h];
+    }
+    for (int h = 0; h < NS; ++h) {
+        views[h] = clip_view(m, b0[h], h);
+        auto hit = m->graphs.find(keys[h]);
+        if (hit != m->graphs.end()) { hit->second.last_use = ++m->graph_clock; continue; }
+        if (int rc = evict_graphs(m, keys, NS)) return rc;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         HIPCHK(m, hipStreamBeginCapture(st[h], hipStreamCaptureModeThreadLocal));
         m->in_graph_body = true;
         m->view = &views[h];
-        run_chunk_body(m, b0[h + 1] - b0[h], st[h], nre);
+        run_chunk_body(m, b0[h + 1] - b0[h], st[h], nres[h]);
         m->view = nullptr;
         m->in_graph_body = false;
         HIPCHK(m, hipStreamEndCapture(st[h], &graph));
         HIPCHK(m, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         (void)hipGraphDestroy(graph);
-        m->graphs.emplace(key, exec);
+        m->graphs.emplace(keys[h], artalk_model::GraphEntry{exec, ++m->graph_clock});
+        ++m->graph_captures;
     }
     if (NS > 1) {
         HIPCHK(m, hipEventRecord(m->fork_ev, s));
         for (int h = 1; h < NS; ++h) HIPCHK(m, hipStreamWaitEvent(st[h], m->fork_ev, 0));
     }
-    for (int h = 0; h < NS; ++h) HIPCHK(m, hipGraphLaunch(m->graphs[keys[h]], st[h]));
+    for (int h = 0; h < NS; ++h) HIPCHK(m, hipGraphLaunch(m->graphs[keys[h]].exec, st[h]));
     for (int h = 1; h < NS; ++h) {
         HIPCHK(m, hipEventRecord(m->join_ev[h - 1], st[h]));
         HIPCHK(m, hipStreamWaitEvent(s, m->join_ev[h - 1], 0));
@@ -1042,7 +1067,7 @@ int reserve(artalk_model* m, int maxB, int maxC) {
     // grow: drop the old workspace (and the graphs that captured its pointers) and allocate the larger one
     maxB = std::max(maxB, m->ws.maxB); maxC = std::max(maxC, m->ws.maxC);
     (void)hipDeviceSynchronize();
-    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
+    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second.exec);
     m->graphs.clear();
     for (void* p : m->ws_allocs) if (p) (void)hipFree(p);
     m->ws_allocs.clear();
@@ -1062,7 +1087,6 @@ int reserve(artalk_model* m, int maxB, int maxC) {
     w.h0 = F(M * Hs); w.h1 = F(M * Hs); w.xln = F(M * Hs); w.qkv = F(M * 3 * Hs); w.att = F(M * Hs); w.ffn = F(M * c.w2v_ffn);
     w.silu_cond = F((int64_t)maxC * kNTok * kCond);
     w.ada = F((int64_t)maxB * kNTok * m->ada_n);
-    if (m->ada_overlap) w.ada2 = F((int64_t)maxB * kNTok * m->ada_n);      // the table of chunk index j + 1 is written while the body of index j reads its own
     w.style_cond = F((int64_t)maxB * kE);
     w.prev_in = F((int64_t)maxB * kNTok * kE); w.prev_in_p8 = F((int64_t)maxB * kNTok * kE);
     w.cache = F((int64_t)c.ar_depth * maxB * 2 * kNTok * 3 * kE);
@@ -1111,8 +1135,6 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return ARTALK_EHIP; }
     artalk_model* m = new artalk_model();
     m->cfg = c; m->device = device_id;
-    if (const char* e = getenv("ARTALK_ADA_OVERLAP")) m->ada_overlap = atoi(e) != 0;      // A/B switch: 0 = the table GEMM in line, in front of every body
-    if (const char* e = getenv("ARTALK_ADA_CUS")) m->ada_cus = std::max(8, atoi(e));
     if (const char* e = getenv("ARTALK_FUSE_QKV_REDUCE")) m->fuse_qkv_reduce = atoi(e) != 0;
     // conv stack geometry: T_l valid frames; row stride S_l per chunk with S_l = 2*S_{l+1} so that one GEMM covers all chunks
     int T = kSamplesPerChunk;
@@ -1140,7 +1162,7 @@ void artalk_destroy(artalk_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     (void)hipDeviceSynchronize();
-    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
+    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second.exec);
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     for (int i = 0; i < 3; ++i) {
@@ -1148,9 +1170,6 @@ void artalk_destroy(artalk_model* m) {
         if (m->join_ev[i]) (void)hipEventDestroy(m->join_ev[i]);
     }
     if (m->fork_ev) (void)hipEventDestroy(m->fork_ev);
-    if (m->ada_stream) (void)hipStreamDestroy(m->ada_stream);
-    for (int i = 0; i < 2; ++i) { if (m->ada_done[i]) (void)hipEventDestroy(m->ada_done[i]); if (m->body_done[i]) (void)hipEventDestroy(m->body_done[i]); }
-    if (m->ada_pre) (void)hipEventDestroy(m->ada_pre);
     free_stage(m);
     for (auto& st : m->stage) if (st.done) (void)hipEventDestroy(st.done);
     if (m->h_status) (void)hipHostFree(m->h_status);
@@ -1310,9 +1329,16 @@ int artalk_set_graphs(artalk_model* m, int enable) {
         m->splitk_tiles = ((enable >> 16) & 0xff) * 16; m->splitk_target = ((enable >> 24) & 0xff) * 16;
     }
     (void)hipSetDevice(m->device); (void)hipDeviceSynchronize();
-    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
+    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second.exec);
     m->graphs.clear();
+    m->init_hist[0].valid = m->init_hist[1].valid = false;      // "the same run_reencode as every later history": the split-K tuning changed
     return ARTALK_OK;
+}
+// number of captured body graphs the model holds (bounded: run_chunk_body_graphs) / captures since the model was created
+int artalk_graph_count(const artalk_model* m, long long* captures) {
+    if (!m) return ARTALK_EINVAL;
+    if (captures) *captures = m->graph_captures;
+    return (int)m->graphs.size();
 }
 
 // Headroom audit of the f16x3 operand format (tools/p8_headroom.py): while enabled, every artalk_infer runs without graphs and
@@ -1387,14 +1413,9 @@ int artalk_set_cu_mask(artalk_model* m, const uint32_t* mask, int n_words) {
         if (m->side_stream[i]) { (void)hipStreamDestroy(m->side_stream[i]); m->side_stream[i] = nullptr; }
         if (m->join_ev[i]) { (void)hipEventDestroy(m->join_ev[i]); m->join_ev[i] = nullptr; }
     }
-    if (m->ada_stream) { (void)hipStreamDestroy(m->ada_stream); m->ada_stream = nullptr; }      // re-created (masked) on demand, with its events
-    for (int i = 0; i < 2; ++i) {
-        if (m->ada_done[i]) { (void)hipEventDestroy(m->ada_done[i]); m->ada_done[i] = nullptr; }
-        if (m->body_done[i]) { (void)hipEventDestroy(m->body_done[i]); m->body_done[i] = nullptr; }
-    }
-    if (m->ada_pre) { (void)hipEventDestroy(m->ada_pre); m->ada_pre = nullptr; }
-    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);      // the GEMM grids were captured for the old CU count
+    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second.exec);      // the GEMM grids were captured for the old CU count
     m->graphs.clear();
+    m->init_hist[0].valid = m->init_hist[1].valid = false;
     return ARTALK_OK;
 }
 
@@ -1419,6 +1440,7 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
             encode_style |= has_style[b] == 1;
         }
     }
+    if (m->tap && (B > m->tap_B || maxch > m->tap_maxch)) return fail(m, ARTALK_EINVAL, "the tap buffer (artalk_set_tap) is smaller than this call");
     if (B > m->ws.maxB || C > m->ws.maxC) { if (int rc = reserve(m, B, (int)C)) return rc; }
     Workspace& w = m->ws;
     // chunk list, chunk-index major: chunk (j, b) for all b with n_chunks[b] > j  -> active clips are a prefix
@@ -1459,60 +1481,27 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
                                    hipMemcpyDeviceToDevice, s));
     stage_mark(m, s, PB_VAE);
     const bool graphs = m->use_graphs && m->profiling != 2 && !m->audit && !m->tap;
-    if (m->tap && (B > m->tap_B || maxch > m->tap_maxch)) return fail(m, ARTALK_EINVAL, "the tap buffer (artalk_set_tap) is smaller than this call");
-    // AdaLN table of a chunk index for all blocks + head: SiLU(cond) @ [W_0;...;W_11;W_head]^T.  Overlapped schedule (graphs on, two
-    // tables): the table of index j + 1 is computed on ada_stream, on ada_cus of the CUs, while body j runs - the body starts with its
-    // latency-bound scale steps 0-2, which leave most CUs idle.  Table j + 2 reuses the buffer of table j: it waits for body j.
-    const bool overlap = graphs && m->ada_overlap && w.ada2 && maxch > 1;
-    if (overlap) {
-        if (!m->ada_stream) {
-            if (m->cu_mask.empty()) HIPCHK(m, hipStreamCreateWithFlags(&m->ada_stream, hipStreamNonBlocking));
-            else HIPCHK(m, hipExtStreamCreateWithCUMask(&m->ada_stream, (uint32_t)m->cu_mask.size(), m->cu_mask.data()));
-            for (int i = 0; i < 2; ++i) {
-                HIPCHK(m, hipEventCreateWithFlags(&m->ada_done[i], hipEventDisableTiming));
-                HIPCHK(m, hipEventCreateWithFlags(&m->body_done[i], hipEventDisableTiming));
-            }
-            HIPCHK(m, hipEventCreateWithFlags(&m->ada_pre, hipEventDisableTiming));
-        }
-        HIPCHK(m, hipEventRecord(m->ada_pre, s));                       // wav2vec2 (silu_cond) is complete, the previous call is done with both tables
-        HIPCHK(m, hipStreamWaitEvent(m->ada_stream, m->ada_pre, 0));
-    }
-    auto ada_table = [&](int64_t j, hipStream_t st, float* dst, int cus) {
+    // AdaLN table of a chunk index for all blocks + head: SiLU(cond) @ [W_0;...;W_11;W_head]^T, in line in front of the body that reads it.
+    // (The table of chunk index j + 1 on a stream of its own beside body j was measured in round 4 and removed in round 5: the bodies slow
+    // down by what the table GEMM takes, profiles/r04_ada_overlap_sweep.log.)
+    auto ada_table = [&](int64_t j) {
         roctxRangePushA("artalk.ar.adaln_table");
-        m->cus_override = cus;
-        linear(m, w.silu_cond + (long)base[j] * kNTok * kCond, kCond, m->ada_w, m->ada_b, dst, m->ada_n, Bj[j] * kNTok, m->ada_n, kCond,
-               ACT_NONE, nullptr, st, m->precision == 1 ? LF_A_P8 : 0);
-        m->cus_override = 0;
+        linear(m, w.silu_cond + (long)base[j] * kNTok * kCond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, Bj[j] * kNTok, m->ada_n, kCond,
+               ACT_NONE, nullptr, s, m->precision == 1 ? LF_A_P8 : 0);
         roctxRangePop();
     };
-    auto enqueue_ada = [&](int64_t j) -> int {       // (overlapped schedule) table j on ada_stream
-        if (j >= maxch) return ARTALK_OK;
-        if (j >= 2) HIPCHK(m, hipStreamWaitEvent(m->ada_stream, m->body_done[j & 1], 0));      // body j - 2 has read this buffer
-        ada_table(j, m->ada_stream, (j & 1) ? w.ada2 : w.ada, j == 0 ? 0 : m->ada_cus);         // table 0 has the chip to itself
-        HIPCHK(m, hipEventRecord(m->ada_done[j & 1], m->ada_stream));
-        return ARTALK_OK;
-    };
-    if (overlap) {
-        if (int rc = enqueue_ada(0)) return rc;
-        if (int rc = enqueue_ada(1)) return rc;
-    }
     for (int64_t j = 0; j < maxch; ++j) {
         const int Bn = Bj[j];
         m->tap_chunk = (int)j;
         // clips whose motion must be re-encoded into a history: those with a chunk j + 1 (a prefix: clips are sorted by length) - all of
         // them when the caller asked for the history bits of every chunk (the reference computes the trailing ones too and drops them)
         const int n_next = out_hist_bits_dev ? Bn : (j + 1 < maxch ? Bj[j + 1] : 0);
-        if (overlap) HIPCHK(m, hipStreamWaitEvent(s, m->ada_done[j & 1], 0));
-        else ada_table(j, s, w.ada, 0);
-        stage_mark(m, s, PB_ADA);       // (overlapped schedule: the time this stream WAITED for the table)
+        ada_table(j);
+        stage_mark(m, s, PB_ADA);
         if (graphs) {
             Range r_body("artalk.body.graph");
-            if (int brc = run_chunk_body_graphs(m, Bn, s, overlap ? (int)(j & 1) : 0, n_next)) return brc;
+            if (int brc = run_chunk_body_graphs(m, Bn, s, n_next)) return brc;
             stage_mark(m, s, PB_AR);   // light profiling: the whole captured body (AR steps + VAE) is charged to the AR bucket
-            if (overlap) {
-                HIPCHK(m, hipEventRecord(m->body_done[j & 1], s));
-                if (int rc = enqueue_ada(j + 2)) return rc;
-            }
         } else {
             if (int brc = run_chunk_body_split(m, Bn, s, n_next)) return brc;
         }

@@ -217,6 +217,12 @@ class BitwiseARModel:
         tuning knobs (multiples of 16, 0 = keep)."""
         capi.lib().artalk_set_graphs(self._h, int(bool(on)) | (int(branches) << 8) | ((splitk_tiles // 16) << 16) | ((splitk_target // 16) << 24))
 
+    def graph_count(self):
+        """(graphs held, captures so far): the body-graph cache is bounded (artalk_graph_count)."""
+        n = C.c_longlong(0)
+        held = capi.lib().artalk_graph_count(self._h, C.byref(n))
+        return int(held), int(n.value)
+
     def set_cu_mask(self, words: Optional[Sequence[int]]):
         """Run this model on a subset of the GPU's compute units (``words``: 32-bit mask words, bit i = CU i // 8 of XCD i % 8 on
         MI355X; None = the whole device): its stream and the library's side streams are created with that mask
@@ -436,6 +442,8 @@ class BitwiseARModel:
         """
         if not self._loaded:
             raise RuntimeError("load_state_dict must be called before inference")
+        if taps and not return_aux:
+            raise ValueError("taps=True needs return_aux=True (the taps are handed back through last_aux)")
         L = capi.lib()
         B = len(audios)
         if B == 0:

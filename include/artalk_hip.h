@@ -156,6 +156,10 @@ int artalk_set_precision(artalk_model* m, int mode);
  * Bits 16-23 / 24-31, when non-zero, override the split-K policy in units of 16 tiles (split when a GEMM has fewer output
  * tiles than the first, aim for the second; defaults 192 / 384 measured best). */
 int artalk_set_graphs(artalk_model* m, int enable);
+/* Number of captured body graphs the model holds; *captures (nullable) = captures since the model was created.  The cache is bounded:
+ * a group's re-encode count is rounded up to a multiple of 8 and at most 96 executables are kept (least recently used evicted), so a
+ * serving loop with ever-changing ragged batches (reference: one clip per call, inference.py:47-57) cannot grow it without limit. */
+int artalk_graph_count(const artalk_model* m, long long* captures);
 /* Headroom audit of the f16x3 operand format: while enabled every artalk_infer runs without graphs and records, for each
  * producer of a P8 operand (LayerNorm outputs, GEMM results written in P8, attention outputs, ...), max |x| * 16 - the value that
  * must stay below fp16's 65504.  artalk_get_audit synchronises and returns the number of sites; names_buf receives the site

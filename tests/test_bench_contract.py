@@ -21,6 +21,12 @@ def test_committed_bench_line_keeps_the_contract(path):
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
     assert d["vs_baseline"] is None                       # BASELINE.md holds no published number for this metric
     assert "workload" in d["config"] and "model" not in d["config"]
+    # SURVEY 8(d) quotes the metric "incl. H2D of audio and D2H of results"; since round 4 `value` is measured with the inputs resident in
+    # HBM (the round's measurement contract), so the line must say which placement `value` has (config.io) AND carry the other one beside
+    # it: the 8(d) figure can never silently disappear.
+    assert "io" in d["config"], "config.io (placement of the inputs for `value`) is missing"
+    sib = "host_io" if "resident in HBM" in d["config"]["io"] else "resident"
+    assert sib in d and d[sib]["value"] > 0 and d[sib]["ms_per_step"] > 0 and "io" in d[sib], f"the `{sib}` sibling figure is missing"
     # value = clips x frames per clip of one step / step time, over all ranks
     c = d["config"]
     rate = d["n_gpus"] * c["clips_per_gpu"] * c["frames_per_clip"] / (d["ms_per_step"] * 1e-3)

@@ -215,3 +215,99 @@ def test_as_rank_walks_the_shards_of_a_larger_job_locally():
     import pytest
     with pytest.raises(AssertionError):
         run_sharded(_fake_infer, audios, None, gather=True, as_rank=(0, 4))
+
+
+# ---- 8-rank readiness without hardware: BASELINE configs[3]'s partition on gloo, world size 8 ----
+class _Cfg3Clips:
+    """configs[3]: clips of equal length (the real ones are 160 000 samples; 1 600 here keep the eight CPU ranks within seconds - the
+    partition, the padding and the collective do not depend on the length).  Lazy: only the local shard may be built."""
+    def __init__(self, n, ragged=False):
+        self.n, self.ragged, self.built = n, ragged, []
+
+    def __len__(self):
+        return self.n
+
+    def n_samples(self, i):
+        return 1600 + (640 * (i % 5) if self.ragged else 0)
+
+    def __getitem__(self, i):
+        self.built.append(i)
+        return torch.full((self.n_samples(i),), float(i + 1))
+
+
+def _worker8(rank, world, port, n_clips, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    try:
+        for ragged in (False, True):
+            clips = _Cfg3Clips(n_clips, ragged)
+            lengths = [seq_length(clips.n_samples(i)) for i in range(n_clips)]
+            calls, reads = [], []
+            orig, orig_cpu = dist.all_gather_into_tensor, torch.Tensor.cpu
+            dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            torch.Tensor.cpu = lambda self, *a, **k: (reads.append(1), orig_cpu(self, *a, **k))[1]
+            res = run_sharded(_fake_infer, clips, None, gather=True, lengths=lengths)
+            dist.all_gather_into_tensor, torch.Tensor.cpu = orig, orig_cpu
+            ok = ok and len(calls) == 1 and not reads                                      # ONE collective, nothing read back
+            ok = ok and sorted(clips.built) == list(shard_range(n_clips, rank, world))      # only the local shard was built
+            ok = ok and len(res) == n_clips
+            for i in range(n_clips):                                                          # input order, every clip once, right length
+                T = lengths[i]
+                want0 = float(i + 1)
+                ok = ok and tuple(res[i].shape) == (T, 106) and float(res[i][0, 0]) == want0 and float(res[i][T - 1, 105]) == want0 + T - 1
+        # the length assert must fire on EVERY rank of an 8-rank job too (a rank that passed it alone would hang the others in the collective)
+        clips = _Cfg3Clips(n_clips, True)
+        try:
+            run_sharded(_short_infer, clips, None, gather=True, lengths=[seq_length(clips.n_samples(i)) for i in range(n_clips)])
+            ok = False
+        except AssertionError as e:
+            ok = ok and "host-derived length" in str(e)
+    except Exception as e:      # noqa: BLE001 - reported through the queue
+        ok = False
+        print(f"rank {rank}: {type(e).__name__}: {e}", flush=True)
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def _run8(n_clips):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, n_clips, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, True) for r in range(8)]
+
+
+def test_config3_partition_world8():
+    """BASELINE configs[3]: 256 clips over 8 ranks = 8 shards of 32, rank-major order = input order, one all-gather, no read-back."""
+    _run8(256)
+
+
+def test_config3_ragged_250_clips_world8():
+    """250 clips over 8 ranks: shards of 31 and 32 (empty-slot padding in the gather buffer), ragged lengths."""
+    sizes = [len(shard_range(250, r, 8)) for r in range(8)]
+    assert sorted(set(sizes)) == [31, 32] and sum(sizes) == 250
+    _run8(250)
+
+
+def test_bench_self_launch_relays_failure_at_8_ranks():
+    """The same GPU-free-parent relay as above at ``--gpus 8`` (the driver's SCALE run): eight ranks are started on 127.0.0.1 and, where
+    there are not eight GPUs, their failure comes back as a non-zero exit status with no result line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        import pytest
+        pytest.skip("eight GPUs present: the ranks would run the real benchmark")
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                           "--no-alt-mode"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert proc.returncode != 0
+    assert "torch.distributed.run" in proc.stderr and "--nproc-per-node=8" in proc.stderr and "127.0.0.1" in proc.stderr
+    assert '"metric"' not in proc.stdout

@@ -283,15 +283,14 @@ np.savez(sys.argv[2], **res)
 """
 
 
-@pytest.mark.parametrize("switch", ["ARTALK_FUSE_QKV_REDUCE", "ARTALK_ADA_OVERLAP"])
+@pytest.mark.parametrize("switch", ["ARTALK_FUSE_QKV_REDUCE"])
 def test_fused_qkv_reduce_is_bit_identical(tmp_path, switch):
     """With ARTALK_FUSE_QKV_REDUCE=1 the 1- / 5-token scale steps leave the split-K slabs of their q|k|v GEMM to the short-query
     attention kernel, whose lanes sum the rows they need straight into their fragment registers (engine.hip run_chunk_body,
     attention.hip AttnArgs::slabs): one launch less per block (measured: not faster, so it is off by default - DESIGN.md section 3).
     Same order of additions as the separate reduce pass, so every code and bit must be IDENTICAL between the arms (switch read at
     model creation: each arm runs in a child process), for a ragged batch of 5 and for batch 1, in both precisions.
-    ARTALK_ADA_OVERLAP=1 (the AdaLN table of chunk index j + 1 on a stream of its own beside body j, two tables, graphs keyed by table
-    parity; also measured and off by default) is held to the same bar: same kernels on other streams, identical results."""
+    (The overlapped AdaLN-table schedule that shared this test in round 4 was a measured loss and is gone: profiles/r04_ada_overlap_sweep.log.)"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     arms = []
@@ -302,3 +301,39 @@ def test_fused_qkv_reduce_is_bit_identical(tmp_path, switch):
     for k in arms[0].files:
         assert np.isfinite(arms[0][k]).all() or arms[0][k].dtype == np.uint8
         assert np.array_equal(arms[0][k], arms[1][k]), k
+
+
+def test_graph_cache_is_bounded_for_ragged_batches():
+    """the body graphs are keyed by (active clips, clip group, precision, re-encoded clips).  A serving loop with varied clip
+    lengths used to add a key per distinct (B_j, B_j+1) pair - O(B^2) executables, never evicted.  Now a group's re-encode count is
+    rounded up to a multiple of 8 (re-encoding a clip without a next chunk is what the reference does, app/models.py:111-114) and the cache
+    is an LRU of at most 96 executables.  Here: 40 calls with random ragged batches of 9..16 tiny clips (1..3 chunks each); the cache
+    must stay within its bound, the SAME ragged batch twice must capture nothing new, and results must equal the single-clip runs'
+    decisions (the bar of test_ragged_batch: identical bits)."""
+    from artalk_amd.synth import synth_audio
+    m = get_gpu_model("tiny")
+    m.set_precision("f16x3")
+    rng = np.random.default_rng(5)
+    lens = [2.0, 4.0, 5.5, 8.0, 9.0, 11.9]
+    clips = {(i, s): torch.from_numpy(synth_audio(900 + i, s)) for i in range(16) for s in lens}
+    held0, cap0 = m.graph_count()
+    for it in range(40):
+        B = int(rng.integers(9, 17))
+        audios = [clips[(i, lens[int(rng.integers(0, len(lens)))])] for i in range(B)]
+        m.inference_batch(audios)
+        held, cap = m.graph_count()
+        assert held <= 96, held
+    # per active-batch size B (9..16 here, and every smaller B a ragged batch decays to) a group of g clips has at most 1 + ceil(g / 8) keys
+    assert cap - cap0 <= 16 * 2 * 3, f"{cap - cap0} captures for 40 ragged calls: the key space is not bounded"
+    audios = [clips[(i, lens[i % len(lens)])] for i in range(12)]
+    outs = m.inference_batch(audios, None, return_aux=True)
+    bits = [b.cpu() for b in m.last_aux["bits"]]
+    _, cap1 = m.graph_count()
+    outs2 = m.inference_batch(audios, None, return_aux=True)
+    assert m.graph_count()[1] == cap1, "the same ragged batch captured new graphs the second time"
+    for a, b in zip(outs, outs2):
+        assert torch.equal(a, b)
+    for i in (0, 5, 11):
+        m.inference_batch([audios[i]], None, return_aux=True)
+        assert torch.equal(m.last_aux["bits"][0].cpu(), bits[i]), f"clip {i}: ragged-batch decisions differ from the single run"
+    assert m.status() == 0
