@@ -20,7 +20,7 @@ DTYPE_F32, DTYPE_I64 = 0, 1
 SYMBOLS = [
     "artalk_create", "artalk_destroy", "artalk_last_error", "artalk_set_tensor", "artalk_finalize_weights",
     "artalk_reserve", "artalk_workspace_bytes", "artalk_weight_bytes", "artalk_infer", "artalk_get_status", "artalk_poll_status", "artalk_last_ticket", "artalk_get_status_of", "artalk_style_encode", "artalk_stream_begin", "artalk_stream_chunk", "artalk_stream_end", "artalk_savgol", "artalk_flame_create", "artalk_flame_verts", "artalk_flame_destroy", "artalk_flame_last_error",
-    "artalk_set_profiling", "artalk_get_profile", "artalk_set_graphs", "artalk_graph_count", "artalk_set_cu_mask", "artalk_set_audit", "artalk_get_audit", "artalk_set_tap", "artalk_tap_layout", "artalk_set_precision",
+    "artalk_set_profiling", "artalk_get_profile", "artalk_set_graphs", "artalk_graph_count", "artalk_set_cu_mask", "artalk_set_audit", "artalk_get_audit", "artalk_calibrate", "artalk_reset_scales", "artalk_get_scales", "artalk_set_tap", "artalk_tap_layout", "artalk_set_precision",
     "artalk_op_gemm", "artalk_op_gemm_ex", "artalk_op_gemm_f16s", "artalk_op_pack_split", "artalk_op_gemm_f16s_packed", "artalk_op_release_scratch", "artalk_op_gemm_p8_plan", "artalk_op_create_masked_stream", "artalk_op_destroy_stream", "artalk_op_mfma_f32_peak", "artalk_op_layernorm", "artalk_op_attention", "artalk_op_w2v_front", "artalk_op_resample_mean", "artalk_op_pool_silu",
     "artalk_op_bsq_history",
 ]
@@ -140,6 +140,13 @@ def lib() -> C.CDLL:
         L.artalk_set_audit.restype = i32
         L.artalk_get_audit.argtypes = [vp, C.c_char_p, i32, C.POINTER(C.c_float), i32]
         L.artalk_get_audit.restype = i32
+    if hasattr(L, "artalk_calibrate"):      # (round 5)
+        L.artalk_calibrate.argtypes = [vp, f32]
+        L.artalk_calibrate.restype = i32
+        L.artalk_reset_scales.argtypes = [vp]
+        L.artalk_reset_scales.restype = i32
+        L.artalk_get_scales.argtypes = [vp, C.POINTER(C.c_int), i32]
+        L.artalk_get_scales.restype = i32
     L.artalk_op_gemm.argtypes = [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.artalk_op_gemm.restype = i32
     L.artalk_set_precision.argtypes = [vp, i32]

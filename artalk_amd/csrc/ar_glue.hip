@@ -78,10 +78,10 @@ __device__ __forceinline__ float area_pool(const float* f, int pn, int i, int c)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Headroom audit (artalk_set_audit): max |x| * 16 over a P8 buffer (the hi halves are f16(16 x)) or over an fp32 buffer that a
-// register-staged GEMM splits while staging; positive floats order like their bit patterns, so the maximum is an atomicMax.
+// Headroom audit (artalk_set_audit): max |x| over a P8 buffer (the hi halves are f16(2^e x): inv_scale = 2^-e) or over an fp32 buffer;
+// positive floats order like their bit patterns, so the maximum is an atomicMax.
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ buf, int rows, int cols, long ld, int is_p8,
-                                                     unsigned int* __restrict__ slot, int junk_period, int junk_from) {
+                                                     unsigned int* __restrict__ slot, int junk_period, int junk_from, float inv_scale) {
     float m = 0.f;
     const long groups = (long)rows * (cols / 8);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < groups; i += (long)gridDim.x * 256) {
@@ -91,21 +91,27 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ b
         if (is_p8) {
             const _Float16* h = reinterpret_cast<const _Float16*>(p);      // [8 x hi][8 x lo]
 #pragma unroll
-            for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)h[e]));
+            for (int e = 0; e < 8; ++e) {
+                const float v = fabsf((float)h[e]) * inv_scale;
+                m = (v != v) ? INFINITY : fmaxf(m, v);      // (a NaN reports as an overflow instead of vanishing in fmaxf)
+            }
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(p[e]) * kActScale);
+            for (int e = 0; e < 8; ++e) {
+                const float v = fabsf(p[e]);
+                m = (v != v) ? INFINITY : fmaxf(m, v);
+            }
         }
     }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
 }
-void launch_absmax(const float* buf, int rows, int cols, long ld, int is_p8, unsigned int* slot, hipStream_t s, int junk_period, int junk_from) {
+void launch_absmax(const float* buf, int rows, int cols, long ld, int is_p8, unsigned int* slot, hipStream_t s, int junk_period, int junk_from, int p8_exp) {
     if (rows <= 0 || cols < 8) return;
     const long groups = (long)rows * (cols / 8);
     const long blocks = (groups + 255) / 256;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, buf, rows, cols, ld, is_p8, slot, junk_period,
-                       junk_from);
+                       junk_from, p8_scale_of(-p8_exp));
 }
 
 // ------------------------------------------------------------------------------------------------

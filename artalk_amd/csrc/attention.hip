@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
             const int d0 = NDT * (4 * g + reg);
             if constexpr (NDT == 4) {
                 const float o0 = ot[0][reg] * inv, o1 = ot[1][reg] * inv, o2 = ot[2][reg] * inv, o3 = ot[3][reg] * inv;
-                if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status);   // op is 32-byte aligned (HD % 8 == 0)
+                if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status, a.o_exp);   // op is 32-byte aligned (HD % 8 == 0)
                 else { f32x4 o = {o0, o1, o2, o3}; *reinterpret_cast<f32x4*>(op + d0) = o; }
             } else {
                 *reinterpret_cast<float2*>(op + d0) = make_float2(ot[0][reg] * inv, ot[NDT - 1][reg] * inv);
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void attention_short_kernel(const AttnArgs 
         if (q0 + q < a.Lq) {
             const float inv = 1.0f / L;
             float* op = a.O + (long)b * a.o_bstride + (long)(q0 + q) * a.ldo + h * HD;
-            if (a.out_p8) store_p8x4(op, 4 * dc, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv, a.status);
+            if (a.out_p8) store_p8x4(op, 4 * dc, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv, a.status, a.o_exp);
             else { const f32x4 v = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv}; *reinterpret_cast<f32x4*>(op + 4 * dc) = v; }
         }
     }
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
             ql[kb] = h8_t{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
         }
     }
-    const float sfix = QKVP8 ? a.scale / (kActScale * kActScale) : 1.0f;      // scores of P8 operands carry 16 * 16 and no softmax scale yet
+    const float sfix = QKVP8 ? a.scale * p8_scale_of(-2 * a.qkv_exp) : 1.0f;      // scores of P8 operands carry the square of their site scale (16 * 16 by default) and no softmax scale yet
     const int klim = (a.split_q > 0 && qi < a.split_q) ? a.split_k : a.Lk;
     const int qblk_last = min(qblk0 + 63, a.Lq - 1);
     const int lk_wg = (a.split_q > 0 && qblk_last < a.split_q) ? a.split_k : a.Lk;
@@ -628,13 +628,13 @@ __global__ __launch_bounds__(256, 4) void attention_f16_kernel(const AttnArgs a)
     l += lane_xor<16>(l);
     l += lane_xor<32>(l);
     if (qvalid) {
-        const float inv = QKVP8 ? 1.0f / (l * kActScale) : 1.0f / l;      // P8 values carry x16
+        const float inv = QKVP8 ? 1.0f / (l * p8_scale_of(a.qkv_exp)) : 1.0f / l;      // P8 values carry their site scale (x16 by default)
         float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const int d0 = 16 * dt + 4 * g;
             const float o0 = ot[dt][0] * inv, o1 = ot[dt][1] * inv, o2 = ot[dt][2] * inv, o3 = ot[dt][3] * inv;
-            if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status);
+            if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status, a.o_exp);
             else { const f32x4 o = {o0, o1, o2, o3}; *reinterpret_cast<f32x4*>(op + d0) = o; }
         }
     }
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
         if (!wave_active) return;
         const h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
         const h8_t qh[2] = {qvalid ? qh_[0] : z, qvalid ? qh_[1] : z}, ql[2] = {qvalid ? ql_[0] : z, qvalid ? ql_[1] : z};
-        const float sfix = a.scale / (kActScale * kActScale);      // scores of P8 operands carry 16 * 16 and no softmax scale yet
+        const float sfix = a.scale * p8_scale_of(-2 * a.qkv_exp);      // scores of P8 operands carry the square of their site scale (16 * 16 by default) and no softmax scale yet
         const int klim = (a.split_q > 0 && qi < a.split_q) ? a.split_k : a.Lk;
         // attention_f16_kernel decides per 64-query workgroup how far the key loop runs; the same bound here keeps the block sequence
         // (and with it every rounding) of a query identical to that kernel's
@@ -835,13 +835,13 @@ __global__ __launch_bounds__(kWideMaxWaves * 64) void attention_f16_wide_kernel(
         l += lane_xor<16>(l);
         l += lane_xor<32>(l);
         if (qvalid) {
-            const float inv = 1.0f / (l * kActScale);      // P8 values carry x16
+            const float inv = 1.0f / (l * p8_scale_of(a.qkv_exp));      // P8 values carry their site scale (x16 by default)
             float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int d0 = 16 * dt + 4 * g;
                 const float o0 = ot[dt][0] * inv, o1 = ot[dt][1] * inv, o2 = ot[dt][2] * inv, o3 = ot[dt][3] * inv;
-                if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status);
+                if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status, a.o_exp);
                 else { const f32x4 o = {o0, o1, o2, o3}; *reinterpret_cast<f32x4*>(op + d0) = o; }
             }
         }
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(kPPWaves * 64) void attention_f16_pp_kernel(const A
     const bool qvalid = qi < a.Lq;
     const bool wave_active = q0 < a.Lq;
     const int trq = r >> 2, trp = r & 3;
-    const float sfix = a.scale / (kActScale * kActScale);
+    const float sfix = a.scale * p8_scale_of(-2 * a.qkv_exp);
 
     // one buffer of one head: 4 images x R rows, piece idx = (image, n) handled by wave idx % 13
     auto issue_buffer = [&](int item, unsigned char* buf, const int R, int key0) {
@@ -1062,13 +1062,13 @@ __global__ __launch_bounds__(kPPWaves * 64) void attention_f16_pp_kernel(const A
             l += lane_xor<32>(l);
             if (qvalid) {
                 const int b = item / a.H, h = item - b * a.H;
-                const float inv = 1.0f / (l * kActScale);      // P8 values carry x16
+                const float inv = 1.0f / (l * p8_scale_of(a.qkv_exp));      // P8 values carry their site scale (x16 by default)
                 float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const int d0 = 16 * dt + 4 * g;
                     const float o0 = ot[dt][0] * inv, o1 = ot[dt][1] * inv, o2 = ot[dt][2] * inv, o3 = ot[dt][3] * inv;
-                    if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status);
+                    if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status, a.o_exp);
                     else { const f32x4 o = {o0, o1, o2, o3}; *reinterpret_cast<f32x4*>(op + d0) = o; }
                 }
             }
@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(NW * 64) void attention_f16_wide_ar_kernel(const At
             ql[kb] = h8_t{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
         }
     }
-    const float sfix = QKVP8 ? a.scale / (kActScale * kActScale) : 1.0f;      // scores of P8 operands carry 16 * 16 and no softmax scale yet
+    const float sfix = QKVP8 ? a.scale * p8_scale_of(-2 * a.qkv_exp) : 1.0f;      // scores of P8 operands carry the square of their site scale (16 * 16 by default) and no softmax scale yet
     const int klim = (a.split_q > 0 && qi < a.split_q) ? a.split_k : a.Lk;
     // the 64-query workgroup of attention_f16_kernel this wave's queries belong to decides how far its key loop runs there: the same
     // bound here keeps the block sequence of a query identical; the phase loop runs to the furthest bound of the workgroup's waves
@@ -1344,13 +1344,13 @@ __global__ __launch_bounds__(NW * 64) void attention_f16_wide_ar_kernel(const At
     l += lane_xor<16>(l);
     l += lane_xor<32>(l);
     if (qvalid) {
-        const float inv = QKVP8 ? 1.0f / (l * kActScale) : 1.0f / l;      // P8 values carry x16
+        const float inv = QKVP8 ? 1.0f / (l * p8_scale_of(a.qkv_exp)) : 1.0f / l;      // P8 values carry their site scale (x16 by default)
         float* op = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const int d0 = 16 * dt + 4 * g;
             const float o0 = ot[dt][0] * inv, o1 = ot[dt][1] * inv, o2 = ot[dt][2] * inv, o3 = ot[dt][3] * inv;
-            if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status);
+            if (a.out_p8) store_p8x4(op, d0, o0, o1, o2, o3, a.status, a.o_exp);
             else { const f32x4 o = {o0, o1, o2, o3}; *reinterpret_cast<f32x4*>(op + d0) = o; }
         }
     }

@@ -122,48 +122,56 @@ __device__ __forceinline__ void apply_act4(f32x4& v, int act) {
     }
 }
 
-// ---- "P8" split format (gemm_f16s.hip): an operand x is first scaled by a power of two S (activations kActScale, weights
-// kWScale), then every 8 consecutive elements of a row become 32 bytes [8 x f16 hi][8 x f16 lo] with hi = f16(S x) and
-// lo = f16(S x - hi) (UNSCALED residual; gfx950's f16 MFMA honours subnormal inputs - tools/mfma_subnormal_probe.py - so a
-// residual below 2^-14 still carries 2^-25 absolute precision).  Same pitch as fp32.  Because both halves are in one scale,
-// hi*hi + hi*lo + lo*hi accumulate in ONE fp32 accumulator; the GEMM epilogue multiplies by kOutScale = 1/(SA*SW) (exact).
-// Range: |x| < 65504/16 = 4094 for activations, < 255 for weights (overflow -> inf -> status word -> exact-f32 re-run).
+// ---- "P8" split format (gemm_f16s.hip): an operand x is first scaled by a power of two S (activations 2^e with e the SITE
+// EXPONENT of the producing site - kActExp = 4, i.e. 16, unless the model's calibration lowered it for a site with outlier
+// activations, engine.hip SiteScales -, weights kWScale), then every 8 consecutive elements of a row become 32 bytes
+// [8 x f16 hi][8 x f16 lo] with hi = f16(S x) and lo = f16(S x - hi) (UNSCALED residual; gfx950's f16 MFMA honours subnormal inputs -
+// tools/mfma_subnormal_probe.py - so a residual below 2^-14 still carries 2^-25 absolute precision).  Same pitch as fp32.  Because
+// both halves are in one scale, hi*hi + hi*lo + lo*hi accumulate in ONE fp32 accumulator; the GEMM epilogue multiplies by
+// 1 / (SA * SW) (exact: powers of two).  Range: |x| < 65504 / S (4094 at the default 16) for activations, < 255 for weights; an
+// overflow raises the status word at the producer (the host recalibrates the site scales, or falls back to exact f32).
+// Producers and consumers carry the exponent e (an int: kernels.h GemmArgs::a_exp / c_exp, LnArgs::p8_exp, AttnArgs::qkv_exp / o_exp):
+// scale, 1 / scale and the guard threshold are two scalar integer operations away from it.
 constexpr float kActScale = 16.0f, kWScale = 256.0f, kOutScale = 1.0f / (16.0f * 256.0f);
+__host__ __device__ __forceinline__ float p8_scale_of(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }       // 2^e
+__host__ __device__ __forceinline__ float p8_out_scale_of(int a_exp) { return __builtin_bit_cast(float, (unsigned)(127 - a_exp - 8) << 23); }   // 1 / (2^a_exp * kWScale)
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split_f16(float xs, _Float16& hi, _Float16& lo) {   // xs already scaled
     hi = (_Float16)xs;
     lo = (_Float16)(xs - (float)hi);
 }
-// Range guard of every P8 producer: an activation with |x| * kActScale beyond fp16's largest finite value (or a NaN) would become
+// Range guard of every P8 producer: an activation with |x| * S beyond fp16's largest finite value (or a NaN) would become
 // inf in the hi half and poison every product it takes part in; the producer reports it in the model's status word (bit 3,
 // include/artalk_hip.h: artalk_get_status) at the place it happens instead of relying on the NaN reaching a bit decision.
 constexpr int kStatusP8Range = 8;
-// |x| * kActScale <= 65504 (fp16's largest finite value), as a bound on the bit pattern of |x|: finite positive floats order like
+// |x| * 2^e <= 65504 (fp16's largest finite value), as a bound on the bit pattern of |x|: finite positive floats order like
 // their bit patterns and NaN / inf patterns lie above every finite one, so ONE unsigned maximum + ONE compare covers range, inf
-// and NaN (an fmaxf chain would drop NaNs and need a compare per element).
-constexpr unsigned int kP8MaxBits = 0x457FE000u;      // bits of 4094.0f = 65504 / 16
+// and NaN (an fmaxf chain would drop NaNs and need a compare per element).  bits(65504 / 2^e) = bits(65504) - (e << 23).
+constexpr unsigned int kP8MaxBits = 0x457FE000u;      // bits of 4094.0f = 65504 / 16 (e = kActExp)
+__host__ __device__ __forceinline__ unsigned int p8_maxbits_of(int e) { return (unsigned int)(0x477FE000 - e * 0x00800000); }
 __device__ __forceinline__ unsigned int abs_bits(float x) { return __float_as_uint(x) & 0x7FFFFFFFu; }
-__device__ __forceinline__ void p8_guard(int* status, float a, float b, float c, float d) {
+__device__ __forceinline__ void p8_guard(int* status, float a, float b, float c, float d, unsigned int maxbits = kP8MaxBits) {
     if (status) {
         const unsigned int m = max(max(abs_bits(a), abs_bits(b)), max(abs_bits(c), abs_bits(d)));
-        if (m > kP8MaxBits) atomicOr(status, kStatusP8Range);
+        if (m > maxbits) atomicOr(status, kStatusP8Range);
     }
 }
-__device__ __forceinline__ void p8_guard16(int* status, const f32x16& v) {      // one compare for a whole 32x32 MFMA sub-tile
+__device__ __forceinline__ void p8_guard16(int* status, const f32x16& v, unsigned int maxbits = kP8MaxBits) {      // one compare for a whole 32x32 MFMA sub-tile
     if (status) {
         unsigned int m = 0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) m = max(m, abs_bits(v[e]));
-        if (m > kP8MaxBits) atomicOr(status, kStatusP8Range);
+        if (m > maxbits) atomicOr(status, kStatusP8Range);
     }
 }
-// store_p8x4 writes activation elements c..c+3 (c % 4 == 0) of a row whose storage starts at `row`.
-__device__ __forceinline__ void store_p8x4(float* row, int c, float x0, float x1, float x2, float x3, int* status = nullptr) {
-    p8_guard(status, x0, x1, x2, x3);
+// store_p8x4 writes activation elements c..c+3 (c % 4 == 0) of a row whose storage starts at `row`, with site exponent e.
+__device__ __forceinline__ void store_p8x4(float* row, int c, float x0, float x1, float x2, float x3, int* status = nullptr, int e = kActExp) {
+    p8_guard(status, x0, x1, x2, x3, p8_maxbits_of(e));
+    const float sc = p8_scale_of(e);
     const float x[4] = {x0, x1, x2, x3};
     f16x4_t h, l;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f16(x[e] * kActScale, a, b); h[e] = a; l[e] = b; }
+    for (int i = 0; i < 4; ++i) { _Float16 a, b; split_f16(x[i] * sc, a, b); h[i] = a; l[i] = b; }
     unsigned char* g = reinterpret_cast<unsigned char*>(row) + (c >> 3) * 32 + (c & 4) * 2;
     *reinterpret_cast<f16x4_t*>(g) = h;
     *reinterpret_cast<f16x4_t*>(g + 16) = l;
@@ -171,12 +179,13 @@ __device__ __forceinline__ void store_p8x4(float* row, int c, float x0, float x1
 
 // The same for lanes that own ADJACENT runs of 4 columns (lane L: c, lane L+1: c+4 of one 8-group, L even; all 64 lanes active):
 // neighbours trade halves so that each issues ONE 16-byte store (even lane the hi chunk, odd lane the lo chunk) instead of two 8-byte ones.
-__device__ __forceinline__ void store_p8x4_pair(float* row, int c, float x0, float x1, float x2, float x3, int* status = nullptr) {
-    p8_guard(status, x0, x1, x2, x3);
+__device__ __forceinline__ void store_p8x4_pair(float* row, int c, float x0, float x1, float x2, float x3, int* status = nullptr, int pe = kActExp) {
+    p8_guard(status, x0, x1, x2, x3, p8_maxbits_of(pe));
+    const float sc = p8_scale_of(pe);
     const float x[4] = {x0, x1, x2, x3};
     f16x4_t h, l;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f16(x[e] * kActScale, a, b); h[e] = a; l[e] = b; }
+    for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f16(x[e] * sc, a, b); h[e] = a; l[e] = b; }
     const uint2 hu = __builtin_bit_cast(uint2, h), lu = __builtin_bit_cast(uint2, l);
     const bool odd = (c & 4) != 0;
     const unsigned sx = odd ? hu.x : lu.x, sy = odd ? hu.y : lu.y;
@@ -264,10 +273,12 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
         float* const p8dst = dual ? g.c2 : x.C;
         if (P8OK && (g.c_p8 || dual)) {   // N % 8 == 0.  Pairs of 8-column groups (k, k+1): lanes h=0 end up with all of group k, lanes h=1 with group k+1
             if (GUARD && rok) {
+                const unsigned int mb = p8_maxbits_of(g.c_exp);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (col0 + 8 * q + 4 * h < g.N) p8_guard(g.status, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                    if (col0 + 8 * q + 4 * h < g.N) p8_guard(g.status, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], mb);
             }
+            const float csc = p8_scale_of(g.c_exp);
 #pragma unroll
             for (int qp = 0; qp < 2; ++qp) {
                 unsigned int w[2][4];     // [group of the pair][hi.x, hi.y, lo.x, lo.y] of this lane's 4 columns
@@ -277,7 +288,7 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         _Float16 a, b;
-                        split_f16(v[8 * qp + 4 * k + e] * kActScale, a, b);
+                        split_f16(v[8 * qp + 4 * k + e] * csc, a, b);
                         hh[e] = a; ll[e] = b;
                     }
                     const uint2 hu = __builtin_bit_cast(uint2, hh), lu = __builtin_bit_cast(uint2, ll);
@@ -317,10 +328,10 @@ __device__ __forceinline__ void epilogue_tile32(const GemmArgs& g, const EpiCtx&
             if (gp) t *= gp[col];
             if (rp) t += rp[col];
             if (P8OK && g.c_p8) {
-                if (GUARD) p8_guard(g.status, t, 0.f, 0.f, 0.f);
+                if (GUARD) p8_guard(g.status, t, 0.f, 0.f, 0.f, p8_maxbits_of(g.c_exp));
                 _Float16* o = reinterpret_cast<_Float16*>(x.C + crow * g.ldc + (col & ~7));
                 _Float16 hh, ll;
-                split_f16(t * kActScale, hh, ll);
+                split_f16(t * p8_scale_of(g.c_exp), hh, ll);
                 o[col & 7] = hh;
                 o[8 + (col & 7)] = ll;
             } else {
@@ -364,7 +375,8 @@ __device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* 
             for (int e = 0; e < 4; ++e) v[4 * q + e] += res[q][e];
     }
     if (g.c_p8) {
-        if (GUARD) p8_guard16(g.status, v);
+        if (GUARD) p8_guard16(g.status, v, p8_maxbits_of(g.c_exp));
+        const float csc = p8_scale_of(g.c_exp);
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
             unsigned int w[2][4];
@@ -372,7 +384,7 @@ __device__ __forceinline__ void epilogue_tile32_store(const GemmArgs& g, float* 
             for (int k = 0; k < 2; ++k) {
                 f16x4_t hh, ll;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f16(v[8 * qp + 4 * k + e] * kActScale, a, b); hh[e] = a; ll[e] = b; }
+                for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f16(v[8 * qp + 4 * k + e] * csc, a, b); hh[e] = a; ll[e] = b; }
                 const uint2 hu = __builtin_bit_cast(uint2, hh), lu = __builtin_bit_cast(uint2, ll);
                 w[k][0] = hu.x; w[k][1] = hu.y; w[k][2] = lu.x; w[k][3] = lu.y;
             }
@@ -422,10 +434,11 @@ __device__ __forceinline__ void epilogue_row4(const GemmArgs& g, const EpiCtx& x
         v[e] = t + rv[e];
     }
     if (g.c_p8) {
-        if (GUARD && ok) p8_guard(g.status, v[0], v[1], v[2], v[3]);
+        if (GUARD && ok) p8_guard(g.status, v[0], v[1], v[2], v[3], p8_maxbits_of(g.c_exp));
+        const float csc = p8_scale_of(g.c_exp);
         f16x4_t hh, ll;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { _Float16 a, c; split_f16(v[e] * kActScale, a, c); hh[e] = a; ll[e] = c; }
+        for (int e = 0; e < 4; ++e) { _Float16 a, c; split_f16(v[e] * csc, a, c); hh[e] = a; ll[e] = c; }
         const uint2 hu = __builtin_bit_cast(uint2, hh), lu = __builtin_bit_cast(uint2, ll);
         const bool odd = (col & 4) != 0;                      // second half of the 8-group: keeps lo, gives hi away
         const unsigned sx = odd ? hu.x : lu.x, sy = odd ? hu.y : lu.y;

@@ -68,6 +68,20 @@ struct VAELayer { float *lnw, *lnb, *qkv_w, *out_w, *out_b, *m1_w, *m1_b, *m2_w,
 struct VAESide { float *in_w, *in_b, *out_w, *out_b; std::vector<VAELayer> layers; };
 struct StyleLayer { float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1w, *n1b, *n2w, *n2b; };
 
+// Site exponents of the P8 operand format (common.h): every producer of a P8 operand writes it with scale 2^e and every consumer removes
+// the same scale, e = kActExp (16) by default.  artalk_calibrate lowers the exponent of a site whose activations need the range
+// (a real XLS-R-class checkpoint: FFN hidden channels of 1e4 and more) - per SITE, so that one outlier channel in a few layers
+// does not cost the whole model its fast mode.  Indexed like the audit's site names.
+struct SiteExps {
+    int conv[8]; int fp_ln, posconv_in;
+    struct W2V { int ln1, qkv, attn, ln2, ffn; } w2v[64];
+    int silu_cond, hist_tok;
+    struct AR { int ln1, attn, ln2, ffn; } ar[32];
+    struct VAE { int ln, qkv, attn, resid, mlp; } vae[2][16];
+    int vae_enc_in, vae_dec_in, vae_dec_head;
+    SiteExps() { int* p = reinterpret_cast<int*>(this); for (size_t i = 0; i < sizeof(SiteExps) / sizeof(int); ++i) p[i] = kActExp; }
+};
+
 struct Workspace {
     int maxB = 0, maxC = 0, G = 0;   // G = wav2vec2 chunk-group size
     // wav2vec2
@@ -110,6 +124,9 @@ struct artalk_model {
     unsigned int* audit_vals = nullptr;            // device, kAuditSlots floats (as bits)
     std::vector<std::string> audit_names;
     std::map<std::string, int> audit_index;
+    std::vector<int*> audit_exp;                   // the site's exponent (SiteExps member) per audit slot: what artalk_calibrate adjusts
+    SiteExps ex;                                   // site exponents of the P8 format (all kActExp until a calibration lowers some)
+    int scales_changed = 0;                        // sites whose exponent differs from kActExp
     // The INITIAL history of a clip (app/models.py:86-89: encode + quantise an all-zero motion) is a function of the weights only - the
     // same bits, decoder features and history tokens for every clip of every call.  It is computed once per precision mode (for ONE
     // clip, through the same run_reencode as every later history) and broadcast to the batch afterwards; only the style token in
@@ -413,19 +430,26 @@ void stage_mark(artalk_model* m, hipStream_t s, int bucket) {
 // over K, its reduce pass also writes that LayerNorm's output (one launch instead of two) and gemm() returns true; otherwise
 // the caller launches the LayerNorm itself.
 constexpr int kAuditSlots = 1024;
-// audit hook: records max |x| * 16 of a just-produced P8 buffer (or of an fp32 buffer a register-staged GEMM will split)
-void audit(artalk_model* m, const std::string& site, const float* buf, int rows, int cols, long ld, bool is_p8, hipStream_t s,
-           int junk_period = 0, int junk_from = 0) {
-    if (!m->audit || !m->audit_vals || m->precision != 1) return;
-    auto it = m->audit_index.find(site);
+// audit hook: records max |x| of a just-produced P8 buffer (or of the fp32 buffer that holds the same activation in f32 mode, or that a
+// register-staged GEMM will split).  ex = the site's exponent (a SiteExps member of this model): what the buffer was written with, and
+// what artalk_calibrate adjusts from the recorded maximum.  Works in both precision modes: the calibration pass runs in exact-f32
+// mode, where nothing can overflow on the way to a later site.
+void audit(artalk_model* m, const char* site, int idx0, const char* sub, const float* buf, int rows, int cols, long ld, bool is_p8, hipStream_t s,
+           int* ex, int junk_period = 0, int junk_from = 0) {
+    if (!m->audit || !m->audit_vals) return;
+    std::string name = site;
+    if (idx0 >= 0) name += std::to_string(idx0);
+    if (sub) name += sub;
+    auto it = m->audit_index.find(name);
     int idx;
     if (it == m->audit_index.end()) {
         if ((int)m->audit_names.size() >= kAuditSlots) return;
         idx = (int)m->audit_names.size();
-        m->audit_names.push_back(site);
-        m->audit_index.emplace(site, idx);
+        m->audit_names.push_back(name);
+        m->audit_exp.push_back(ex);
+        m->audit_index.emplace(name, idx);
     } else idx = it->second;
-    launch_absmax(buf, rows, cols & ~7, ld, is_p8 ? 1 : 0, m->audit_vals + idx, s, junk_period, junk_from);
+    launch_absmax(buf, rows, cols & ~7, ld, is_p8 ? 1 : 0, m->audit_vals + idx, s, junk_period, junk_from, ex ? *ex : kActExp);
 }
 
 // defer_reduce: the caller's next kernel sums the split-K slabs itself (the short-query attention kernel does, for the q|k|v rows of
@@ -471,6 +495,15 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
             // ~150 tiles the 64x64 kernel wins: projection at M = 1600 14.0 vs 19.0).  It has no second P8 copy of the result (c2).
             if (S == 1 && g.force_cfg < 0 && !g.c2) {
                 const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+                // (experiment, ARTALK_PP: bit 0 = the ping-pong 256 x 128 kernel (cfg 31) for unsplit launches with >= ARTALK_PP_MIN of its
+                // tiles; bit 1 = its 128 x 128 form (cfg 33) in place of the mid-grid kernel)
+                static const int pp_mode = getenv("ARTALK_PP") ? atoi(getenv("ARTALK_PP")) : 0;
+                static const int pp_min = getenv("ARTALK_PP_MIN") ? atoi(getenv("ARTALK_PP_MIN")) : 120;
+                const int t256 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
+                if ((pp_mode & 1) && t256 >= pp_min && t256 <= 256) cfg = 31;
+                else if (t128 >= 150) cfg = (pp_mode & 2) ? 33 : 28;
+                if (cfg == 31 || cfg == 33) g.force_cfg = cfg;
+                else
                 if (t128 >= 150) cfg = 28;
                 else if (g.K >= 2048 && 3 * t128 >= 150 && (int64_t)3 * g.M * g.N <= cw.splitk_floats) { S = 3; cfg = 28; }
                 if (cfg == 28 && S == 1) g.force_cfg = 28;
@@ -510,7 +543,7 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
         else if (defer_reduce && !c2) *defer_reduce = g.splitk;
         else launch_splitk_reduce(g, s);
     }
-    if (c2 && !c2_fused) launch_pack_split(g.C, reinterpret_cast<unsigned int*>(c2), (long)g.M * g.N, false, s, g.status);
+    if (c2 && !c2_fused) launch_pack_split(g.C, reinterpret_cast<unsigned int*>(c2), (long)g.M * g.N, false, s, g.status, g.c_exp);
     if (m->profiling && dominant) {
         next_event(m, s, &i1);
         m->dom_events.emplace_back(i0, gemm_flops(g));
@@ -532,9 +565,9 @@ void tap_copy(artalk_model* m, int field, int row0, const float* src, int rows, 
 enum { LF_EXACT = 1, LF_A_P8 = 2, LF_C_P8 = 4 };   // linear() flags: decision-critical (fp32 path) / A is in P8 / write C in P8
 // plain y = act(x W^T + b) [+ R]
 void linear(artalk_model* m, const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N, int K,
-            int act, const float* R, hipStream_t s, int flags = 0, float* c2 = nullptr) {
+            int act, const float* R, hipStream_t s, int flags = 0, float* c2 = nullptr, int a_exp = kActExp, int c_exp = kActExp) {
     GemmArgs g;
-    g.c2 = c2;
+    g.c2 = c2; g.a_exp = a_exp; g.c_exp = c_exp;
     g.exact = flags & LF_EXACT; g.a_packed = (flags & LF_A_P8) ? 1 : 0; g.c_p8 = (flags & LF_C_P8) ? 1 : 0;
     g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act;
     g.R = R; g.ldr = ldc;
@@ -542,9 +575,9 @@ void linear(artalk_model* m, const float* A, long lda, const float* W, const flo
 }
 
 void layernorm(const float* X, float* Y, const float* w, const float* b, int M, int D, float eps, int act, hipStream_t s, int out_p8 = 0,
-               int* status = nullptr, int junk_period = 0, int junk_from = 0) {
+               int* status = nullptr, int junk_period = 0, int junk_from = 0, int p8_exp = kActExp) {
     LnArgs a;
-    a.out_p8 = out_p8; a.status = out_p8 ? status : nullptr; a.junk_period = junk_period; a.junk_from = junk_from;
+    a.out_p8 = out_p8; a.p8_exp = p8_exp; a.status = out_p8 ? status : nullptr; a.junk_period = junk_period; a.junk_from = junk_from;
     a.X = X; a.ldx = D; a.Y = Y; a.ldy = D; a.w = w; a.b = b; a.M = M; a.D = D; a.eps = eps; a.act = act;
     launch_layernorm(a, s);
 }
@@ -562,20 +595,21 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     Range r_w2v("artalk.wav2vec2");
     roctxRangePushA("artalk.wav2vec2.conv_stack");      // K1-K3: normalise, conv0+LN+GELU, conv1-6 as GEMMs + LN + GELU
     launch_audio_normalize(audio, w.src_off + c0, w.xnorm, n, kSamplesPerChunk, s);
+    SiteExps& ex = m->ex;
     launch_conv0(w.xnorm, kSamplesPerChunk, m->conv0_w, m->conv_b[0], m->conv_lnw[0], m->conv_lnb[0], w.convA, n, m->conv_T[0],
-                 m->conv_S[0], s, p8, w.status);
-    audit(m, "w2v.conv0.ln_gelu", w.convA, n * m->conv_S[0], CD, CD, p8, s, m->conv_S[0], m->conv_T[0]);
+                 m->conv_S[0], s, p8, w.status, ex.conv[0]);
+    audit(m, "w2v.conv", 0, ".ln_gelu", w.convA, n * m->conv_S[0], CD, CD, p8, s, &ex.conv[0], m->conv_S[0], m->conv_T[0]);
     float* src = w.convA; float* dst = w.convB;
     for (int i = 1; i < c.w2v_n_conv; ++i) {
         // stride-2 conv as a GEMM: output row r reads input rows 2r..2r+k-1 (contiguous K = k*512 floats)
         const int M = n * m->conv_S[i];
         linear(m, src, (long)c.w2v_conv_stride[i] * CD, m->conv_w[i], m->conv_b[i], dst, CD, M, CD, c.w2v_conv_kernel[i] * CD,
-               ACT_NONE, nullptr, s, AP);
+               ACT_NONE, nullptr, s, AP, nullptr, ex.conv[i - 1]);
         // the last conv output feeds a LayerNorm (feature projection), not a GEMM: it stays fp32
         // rows t >= conv_T[i] of every chunk are layout padding (computed from the padding rows below them): no range guard there
         layernorm(dst, dst, m->conv_lnw[i], m->conv_lnb[i], M, CD, 1e-5f, ACT_GELU_ERF, s, (p8 && i + 1 < c.w2v_n_conv) ? 1 : 0, w.status,
-                  m->conv_S[i], m->conv_T[i]);
-        if (i + 1 < c.w2v_n_conv) audit(m, "w2v.conv" + std::to_string(i) + ".ln_gelu", dst, M, CD, CD, p8, s, m->conv_S[i], m->conv_T[i]);
+                  m->conv_S[i], m->conv_T[i], ex.conv[i]);
+        if (i + 1 < c.w2v_n_conv) audit(m, "w2v.conv", i, ".ln_gelu", dst, M, CD, CD, p8, s, &ex.conv[i], m->conv_S[i], m->conv_T[i]);
         std::swap(src, dst);
     }
     stage_mark(m, s, PB_CONV);
@@ -587,15 +621,16 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     // everything computed in it stays finite and inside the P8 range without the GEMM epilogues having to know about it.
     const int JP = m->Ts, JF = m->Tw;
     // feature projection (hf:429-434)
-    layernorm(src, dst, m->fp_lnw, m->fp_lnb, M, CD, c.w2v_ln_eps, ACT_NONE, s, p8, w.status, JP, JF);
-    audit(m, "w2v.feature_projection.ln", dst, M, CD, CD, p8, s, JP, JF);
-    linear(m, dst, CD, m->fp_w, m->fp_b, w.h0, Hs, M, Hs, CD, ACT_NONE, nullptr, s, AP);
+    layernorm(src, dst, m->fp_lnw, m->fp_lnb, M, CD, c.w2v_ln_eps, ACT_NONE, s, p8, w.status, JP, JF, ex.fp_ln);
+    audit(m, "w2v.feature_projection.ln", -1, nullptr, dst, M, CD, CD, p8, s, &ex.fp_ln, JP, JF);
+    linear(m, dst, CD, m->fp_w, m->fp_b, w.h0, Hs, M, Hs, CD, ACT_NONE, nullptr, s, AP, nullptr, ex.fp_ln);
     // positional conv embedding (hf:360-368): h1 = h0 + gelu(groupconv(h0) + b)
+    audit(m, "w2v.posconv.input(fp32 A)", -1, nullptr, w.h0, M, Hs, Hs, false, s, &ex.posconv_in, JP, JF);
     {
         const int cg = Hs / c.w2v_pos_groups;
         GemmArgs g;
         g.A = w.h0; g.lda = Hs; g.W = m->pos_w; g.ldw = (long)cg * c.w2v_pos_kernel; g.bias = m->pos_b; g.C = w.h1; g.ldc = Hs; g.R = w.h0; g.ldr = Hs;
-        g.M = M; g.act = ACT_GELU_ERF;
+        g.M = M; g.act = ACT_GELU_ERF; g.a_exp = ex.posconv_in;
         if (p8 && cg == 64 && c.w2v_pos_kernel == 128 && c.w2v_pos_groups == 16 && m->Ts <= 256) {
             // f16x3 mode: one workgroup per (chunk, group) with the chunk's input window resident in LDS (posconv_p8_kernel)
             g.N = Hs; g.K = cg * c.w2v_pos_kernel; g.Wp = packed_of(m, m->pos_w); g.status = w.status;
@@ -612,33 +647,33 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     const int nh = c.w2v_heads, hd = Hs / nh;
     for (int i = 0; i < c.w2v_layers; ++i) {
         const W2VLayer& L = m->w2v[i];
-        const std::string an = "w2v.layer" + std::to_string(i);
-        layernorm(h, w.xln, L.ln1w, L.ln1b, M, Hs, c.w2v_ln_eps, ACT_NONE, s, p8, w.status, JP, JF);
-        audit(m, an + ".ln1", w.xln, M, Hs, Hs, p8, s, JP, JF);
-        linear(m, w.xln, Hs, L.qkv_w, L.qkv_b, w.qkv, 3 * Hs, M, 3 * Hs, Hs, ACT_NONE, nullptr, s, AP | (p8 ? LF_C_P8 : 0));   // q, k, v leave in P8
+        SiteExps::W2V& E = ex.w2v[i];
+        layernorm(h, w.xln, L.ln1w, L.ln1b, M, Hs, c.w2v_ln_eps, ACT_NONE, s, p8, w.status, JP, JF, E.ln1);
+        audit(m, "w2v.layer", i, ".ln1", w.xln, M, Hs, Hs, p8, s, &E.ln1, JP, JF);
+        linear(m, w.xln, Hs, L.qkv_w, L.qkv_b, w.qkv, 3 * Hs, M, 3 * Hs, Hs, ACT_NONE, nullptr, s, AP | (p8 ? LF_C_P8 : 0), nullptr, E.ln1, E.qkv);   // q, k, v leave in P8
         AttnArgs a;
-        a.qkv_p8 = p8;
+        a.qkv_p8 = p8; a.qkv_exp = E.qkv; a.o_exp = E.attn;
         a.Q = w.qkv; a.K = w.qkv + Hs; a.V = w.qkv + 2 * Hs;
         a.ldq = a.ldk = a.ldv = 3 * Hs; a.q_bstride = a.k_bstride = a.v_bstride = (long)m->Ts * 3 * Hs;
         a.O = w.att; a.ldo = Hs; a.o_bstride = (long)m->Ts * Hs;
         a.B = n; a.H = nh; a.HD = hd; a.Lq = m->Tw; a.Lk = m->Tw; a.scale = 1.0f / std::sqrt((float)hd);
-        audit(m, an + ".qkv", w.qkv, M, 3 * Hs, 3 * Hs, p8, s, JP, JF);
+        audit(m, "w2v.layer", i, ".qkv", w.qkv, M, 3 * Hs, 3 * Hs, p8, s, &E.qkv, JP, JF);
         a.out_p8 = p8; a.split16 = p8; a.status = p8 ? w.status : nullptr; a.cus = m->n_cus;
         launch_attention(a, s);
-        audit(m, an + ".attn_out", w.att, M, Hs, Hs, p8, s, JP, JF);
-        linear(m, w.att, Hs, L.out_w, L.out_b, h, Hs, M, Hs, Hs, ACT_NONE, h, s, AP);
-        layernorm(h, w.xln, L.ln2w, L.ln2b, M, Hs, c.w2v_ln_eps, ACT_NONE, s, p8, w.status, JP, JF);
-        audit(m, an + ".ln2", w.xln, M, Hs, Hs, p8, s, JP, JF);
-        linear(m, w.xln, Hs, L.ff1_w, L.ff1_b, w.ffn, c.w2v_ffn, M, c.w2v_ffn, Hs, ACT_GELU_ERF, nullptr, s, AP | (p8 ? LF_C_P8 : 0));
-        audit(m, an + ".ffn_hidden", w.ffn, M, c.w2v_ffn, c.w2v_ffn, p8, s, JP, JF);
-        linear(m, w.ffn, c.w2v_ffn, L.ff2_w, L.ff2_b, h, Hs, M, Hs, c.w2v_ffn, ACT_NONE, h, s, AP);
+        audit(m, "w2v.layer", i, ".attn_out", w.att, M, Hs, Hs, p8, s, &E.attn, JP, JF);
+        linear(m, w.att, Hs, L.out_w, L.out_b, h, Hs, M, Hs, Hs, ACT_NONE, h, s, AP, nullptr, E.attn);
+        layernorm(h, w.xln, L.ln2w, L.ln2b, M, Hs, c.w2v_ln_eps, ACT_NONE, s, p8, w.status, JP, JF, E.ln2);
+        audit(m, "w2v.layer", i, ".ln2", w.xln, M, Hs, Hs, p8, s, &E.ln2, JP, JF);
+        linear(m, w.xln, Hs, L.ff1_w, L.ff1_b, w.ffn, c.w2v_ffn, M, c.w2v_ffn, Hs, ACT_GELU_ERF, nullptr, s, AP | (p8 ? LF_C_P8 : 0), nullptr, E.ln2, E.ffn);
+        audit(m, "w2v.layer", i, ".ffn_hidden", w.ffn, M, c.w2v_ffn, c.w2v_ffn, p8, s, &E.ffn, JP, JF);
+        linear(m, w.ffn, c.w2v_ffn, L.ff2_w, L.ff2_b, h, Hs, M, Hs, c.w2v_ffn, ACT_NONE, h, s, AP, nullptr, E.ffn);
     }
     layernorm(h, w.xln, m->enc_lnw, m->enc_lnb, M, Hs, c.w2v_ln_eps, ACT_NONE, s);
     if (out_w2v)
         (void)hipMemcpy2DAsync(out_w2v + (long)c0 * m->Tw * Hs, (size_t)m->Tw * Hs * 4, w.xln, (size_t)m->Ts * Hs * 4,
                                (size_t)m->Tw * Hs * 4, n, hipMemcpyDeviceToDevice, s);
-    launch_pool_silu(w.xln, m->Ts, m->Tw, w.silu_cond + (long)c0 * kNTok * kCond, n, m->pn, c.n_levels, kCond, s, p8, w.status);
-    audit(m, "ar.silu_cond", w.silu_cond + (long)c0 * kNTok * kCond, n * kNTok, kCond, kCond, p8, s);
+    launch_pool_silu(w.xln, m->Ts, m->Tw, w.silu_cond + (long)c0 * kNTok * kCond, n, m->pn, c.n_levels, kCond, s, p8, w.status, ex.silu_cond);
+    audit(m, "ar.silu_cond", -1, nullptr, w.silu_cond + (long)c0 * kNTok * kCond, n * kNTok, kCond, kCond, p8, s, &ex.silu_cond);
     stage_mark(m, s, PB_ENC);
 }
 
@@ -681,31 +716,33 @@ void run_vae_stack(artalk_model* m, const VAESide& S, int B, int T, int split, h
     const int H = c.vae_hidden, M = B * T, F = H * 3 / 2;
     const int p8 = m->precision == 1 ? 1 : 0;      // GEMM-only activations in the P8 split format (see run_chunk_body)
     const int AP = p8 ? LF_A_P8 : 0;
+    const int sd = &S == &m->enc ? 0 : 1;
+    const char* const an = sd == 0 ? "vae.encoder.layer" : "vae.decoder.layer";
     for (int i = 0; i < c.vae_depth; ++i) {
         const VAELayer& L = S.layers[i];
-        const std::string an = std::string(&S == &m->enc ? "vae.encoder.layer" : "vae.decoder.layer") + std::to_string(i);
-        layernorm(w.vh, w.vln, L.lnw, L.lnb, M, H, 1e-5f, ACT_NONE, s, p8, w.status);
-        audit(m, an + ".ln", w.vln, M, H, H, p8, s);
-        linear(m, w.vln, H, L.qkv_w, nullptr, w.vqkv, 3 * H, M, 3 * H, H, ACT_NONE, nullptr, s, AP | (p8 ? LF_C_P8 : 0));   // q, k, v leave in P8
+        SiteExps::VAE& E = m->ex.vae[sd][i];
+        layernorm(w.vh, w.vln, L.lnw, L.lnb, M, H, 1e-5f, ACT_NONE, s, p8, w.status, 0, 0, E.ln);
+        audit(m, an, i, ".ln", w.vln, M, H, H, p8, s, &E.ln);
+        linear(m, w.vln, H, L.qkv_w, nullptr, w.vqkv, 3 * H, M, 3 * H, H, ACT_NONE, nullptr, s, AP | (p8 ? LF_C_P8 : 0), nullptr, E.ln, E.qkv);   // q, k, v leave in P8
         AttnArgs a;
-        a.qkv_p8 = p8;
+        a.qkv_p8 = p8; a.qkv_exp = E.qkv; a.o_exp = E.attn;
         a.Q = w.vqkv; a.K = w.vqkv + H; a.V = w.vqkv + 2 * H; a.ldq = a.ldk = a.ldv = 3 * H;
         a.q_bstride = a.k_bstride = a.v_bstride = (long)T * 3 * H;
         a.O = w.vatt; a.ldo = H; a.o_bstride = (long)T * H;
         a.B = B; a.H = c.vae_heads; a.HD = H / c.vae_heads; a.Lq = T; a.Lk = T;
         a.scale = 1.0f / std::sqrt((float)H);      // hidden_dim**-0.5, NOT head_dim (bitwise_vae.py:198)
-        audit(m, an + ".qkv", w.vqkv, M, 3 * H, 3 * H, p8, s);
+        audit(m, an, i, ".qkv", w.vqkv, M, 3 * H, 3 * H, p8, s, &E.qkv);
         a.split_q = split; a.split_k = split; a.out_p8 = p8; a.split16 = p8; a.status = p8 ? w.status : nullptr; a.cus = m->n_cus;
         launch_attention(a, s);
-        audit(m, an + ".attn_out", w.vatt, M, H, H, p8, s);
+        audit(m, an, i, ".attn_out", w.vatt, M, H, H, p8, s, &E.attn);
         // the MLP reads the residual stream itself (no LayerNorm in front of it, bitwise_vae.py:139-145).  In f16x3 mode the
         // out-projection writes it a second time in P8 (w.vln) so that the MLP GEMM can stage it by LDS-DMA (the register-staged
         // kernel on fp32 rows took 36 us at M = 6400, a split pass + the small-grid kernel 4 + 15, the second copy from the epilogue 15)
-        linear(m, w.vatt, H, L.out_w, L.out_b, w.vh, H, M, H, H, ACT_NONE, w.vh, s, AP, p8 ? w.vln : nullptr);
-        audit(m, an + ".residual", p8 ? w.vln : w.vh, M, H, H, p8, s);
-        linear(m, p8 ? w.vln : w.vh, H, L.m1_w, L.m1_b, w.vmlp, F, M, F, H, ACT_GELU_TANH, nullptr, s, p8 ? (LF_A_P8 | LF_C_P8) : 0);
-        audit(m, an + ".mlp_hidden", w.vmlp, M, F, F, p8, s);
-        linear(m, w.vmlp, F, L.m2_w, L.m2_b, w.vh, H, M, H, F, ACT_NONE, w.vh, s, AP);
+        linear(m, w.vatt, H, L.out_w, L.out_b, w.vh, H, M, H, H, ACT_NONE, w.vh, s, AP, p8 ? w.vln : nullptr, E.attn, E.resid);
+        audit(m, an, i, ".residual", p8 ? w.vln : w.vh, M, H, H, p8, s, &E.resid);
+        linear(m, p8 ? w.vln : w.vh, H, L.m1_w, L.m1_b, w.vmlp, F, M, F, H, ACT_GELU_TANH, nullptr, s, p8 ? (LF_A_P8 | LF_C_P8) : 0, nullptr, E.resid, E.mlp);
+        audit(m, an, i, ".mlp_hidden", w.vmlp, M, F, F, p8, s, &E.mlp);
+        linear(m, w.vmlp, F, L.m2_w, L.m2_b, w.vh, H, M, H, F, ACT_NONE, w.vh, s, AP, nullptr, E.mlp);
     }
 }
 
@@ -715,8 +752,8 @@ void run_reencode(artalk_model* m, int B, hipStream_t s) {
     Workspace& w = m->view ? *m->view : m->ws;
     const int H = c.vae_hidden, T = 100;
     Range r_re("artalk.vae.reencode_bsq");              // K16-K17: encoder, multi-scale BSQ, history features
-    audit(m, "vae.encoder.input(fp32 A)", w.enc_in, B * T, 128, 128, false, s);
-    linear(m, w.enc_in, 128, m->enc.in_w, m->enc.in_b, w.vh, H, B * T, H, 128, ACT_LEAKY02, nullptr, s);
+    audit(m, "vae.encoder.input(fp32 A)", -1, nullptr, w.enc_in, B * T, 128, 128, false, s, &m->ex.vae_enc_in);
+    linear(m, w.enc_in, 128, m->enc.in_w, m->enc.in_b, w.vh, H, B * T, H, 128, ACT_LEAKY02, nullptr, s, 0, nullptr, m->ex.vae_enc_in);
     run_vae_stack(m, m->enc, B, T, 0, s);
     linear(m, w.vh, H, m->enc.out_w, m->enc.out_b, w.enc_out, c.code_dim, B * T, c.code_dim, H, ACT_NONE, nullptr, s, LF_EXACT);
     launch_bsq_history(w.enc_out, w.hist_bits, w.prev_fdec, w.msfeat, B, s, w.status);
@@ -772,12 +809,13 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s, int n_reencode = -1) 
     // K/V of the 181 history tokens, once per layer (raw prev tokens, not modulated: app/transformer.py:68-70)
     tap_copy(m, TAP_PREV_IN, 0, w.prev_in, kNTok, kE, B, s);      // prev_attn_feat + prev_lvl_pos_embed (app/models.py:101, 2nd argument)
     roctxRangePushA("artalk.ar.history_kv");
-    if (p8) launch_pack_split(w.prev_in, reinterpret_cast<unsigned int*>(w.prev_in_p8), (long)B * kNTok * kE, false, s, w.status);   // one split for the 12 layers
-    audit(m, "ar.history_tokens", p8 ? w.prev_in_p8 : w.prev_in, B * kNTok, kE, kE, p8, s);
+    SiteExps& ex = m->ex;
+    if (p8) launch_pack_split(w.prev_in, reinterpret_cast<unsigned int*>(w.prev_in_p8), (long)B * kNTok * kE, false, s, w.status, ex.hist_tok);   // one split for the 12 layers
+    audit(m, "ar.history_tokens", -1, nullptr, p8 ? w.prev_in_p8 : w.prev_in, B * kNTok, kE, kE, p8, s, &ex.hist_tok);
     {
         // all blocks in one launch: N = depth x (E keys + E values), column group l = block l's weight rows / cache columns
         GemmArgs g;
-        g.A = p8 ? w.prev_in_p8 : w.prev_in; g.a_packed = p8;
+        g.A = p8 ? w.prev_in_p8 : w.prev_in; g.a_packed = p8; g.a_exp = ex.hist_tok;
         g.lda = kE; g.W = m->ar_qkv_w + (long)kE * kE; g.ldw = kE; g.bias = m->ar_qkv_b + kE;
         g.C = w.cache + kE; g.ldc = 3 * kE; g.cmap = rowmap(kNTok, 2 * kNTok, 0);
         g.M = B * kNTok; g.N = c.ar_depth * 2 * kE; g.K = kE;
@@ -812,6 +850,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s, int n_reencode = -1) 
             if (l < c.ar_depth) {
                 const float* ada = w.ada + (long)l * 6 * kE;   // gamma1,gamma2,scale1,scale2,shift1,shift2 (app/transformer.py:32)
                 n.scale = ada + (2 + which) * kE; n.shift = ada + (4 + which) * kE; n.out_p8 = p8;
+                n.p8_exp = which == 0 ? ex.ar[l].ln1 : ex.ar[l].ln2;
             } else {                                           // head (app/models.py:145-148): scale, shift = split2; fp32 (exact logits GEMM)
                 const float* hada = w.ada + (long)c.ar_depth * 6 * kE;
                 n.scale = hada; n.shift = hada + kE; n.out_p8 = 0;
@@ -823,13 +862,13 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s, int n_reencode = -1) 
             const ARLayer& L = m->ar[l];
             const float* ada = w.ada + (long)l * 6 * kE;
             float* cache = w.cache + l * cache_l;
-            const std::string an = "ar.block" + std::to_string(l);
+            SiteExps::AR& E = ex.ar[l];
             if (l == 0) tap_copy(m, TAP_BLK0_IN, off, w.x, pn, kE, B, s);        // attn_feat entering attn_blocks[0] (app/models.py:100)
             if (!have_ln) launch_layernorm(ln_args(l, 0), s);
-            audit(m, an + ".ln1_mod", w.xmod, M, kE, kE, p8, s);
+            audit(m, "ar.block", l, ".ln1_mod", w.xmod, M, kE, kE, p8, s, &E.ln1);
             GemmArgs q;
             q.A = w.xmod; q.lda = kE; q.W = L.qkv_w; q.ldw = kE; q.bias = L.qkv_b; q.C = cache; q.ldc = 3 * kE;
-            q.cmap = rowmap(pn, 2 * kNTok, kNTok + off); q.M = M; q.N = 3 * kE; q.K = kE; q.a_packed = p8;
+            q.cmap = rowmap(pn, 2 * kNTok, kNTok + off); q.M = M; q.N = 3 * kE; q.K = kE; q.a_packed = p8; q.a_exp = E.ln1;
             // 1- and 5-token steps: a split q|k|v GEMM leaves its slabs to the attention kernel, whose workgroup (clip, head) sums the
             // rows of its own head (same order: slabs ascending, then the bias), writes them to the KV cache and goes on - one launch
             // less per block (ARTALK_FUSE_QKV_REDUCE=0: the separate reduce pass; a test compares both arms bit for bit)
@@ -843,20 +882,20 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s, int n_reencode = -1) 
             a.ldq = a.ldk = a.ldv = 3 * kE; a.q_bstride = a.k_bstride = a.v_bstride = (long)2 * kNTok * 3 * kE;
             a.O = w.attn_out; a.ldo = kE; a.o_bstride = (long)pn * kE;
             a.B = B; a.H = c.ar_heads; a.HD = kE / c.ar_heads; a.Lq = pn; a.Lk = kNTok + off + pn; a.scale = 1.0f;
-            a.l2norm = 1; a.qscale = L.qscale; a.out_p8 = p8; a.split16 = p8; a.status = p8 ? w.status : nullptr;
+            a.l2norm = 1; a.qscale = L.qscale; a.out_p8 = p8; a.split16 = p8; a.status = p8 ? w.status : nullptr; a.o_exp = E.attn;
             launch_attention(a, s);
-            audit(m, an + ".attn_out", w.attn_out, M, kE, kE, p8, s);
+            audit(m, "ar.block", l, ".attn_out", w.attn_out, M, kE, kE, p8, s, &E.attn);
             GemmArgs pj;
             pj.A = w.attn_out; pj.lda = kE; pj.W = L.proj_w; pj.ldw = kE; pj.bias = L.proj_b; pj.C = w.x; pj.ldc = kE;
-            pj.gate = ada; pj.ldg = ldada; pj.gmap = amap; pj.R = w.x; pj.ldr = kE; pj.M = M; pj.N = kE; pj.K = kE; pj.a_packed = p8;
+            pj.gate = ada; pj.ldg = ldada; pj.gmap = amap; pj.R = w.x; pj.ldr = kE; pj.M = M; pj.N = kE; pj.K = kE; pj.a_packed = p8; pj.a_exp = E.attn;
             const LnArgs n2 = ln_args(l, 1);
             if (!gemm(m, pj, s, &n2)) launch_layernorm(n2, s);
-            audit(m, an + ".ln2_mod", w.xmod, M, kE, kE, p8, s);
-            linear(m, w.xmod, kE, L.ffn1_w, L.ffn1_b, w.ffn_h, 4 * kE, M, 4 * kE, kE, ACT_GELU_TANH, nullptr, s, p8 ? (LF_A_P8 | LF_C_P8) : 0);
-            audit(m, an + ".ffn_hidden", w.ffn_h, M, 4 * kE, 4 * kE, p8, s);
+            audit(m, "ar.block", l, ".ln2_mod", w.xmod, M, kE, kE, p8, s, &E.ln2);
+            linear(m, w.xmod, kE, L.ffn1_w, L.ffn1_b, w.ffn_h, 4 * kE, M, 4 * kE, kE, ACT_GELU_TANH, nullptr, s, p8 ? (LF_A_P8 | LF_C_P8) : 0, nullptr, E.ln2, E.ffn);
+            audit(m, "ar.block", l, ".ffn_hidden", w.ffn_h, M, 4 * kE, 4 * kE, p8, s, &E.ffn);
             GemmArgs f2;
             f2.A = w.ffn_h; f2.lda = 4 * kE; f2.W = L.ffn2_w; f2.ldw = 4 * kE; f2.bias = L.ffn2_b; f2.C = w.x; f2.ldc = kE;
-            f2.gate = ada + kE; f2.ldg = ldada; f2.gmap = amap; f2.R = w.x; f2.ldr = kE; f2.M = M; f2.N = kE; f2.K = 4 * kE; f2.a_packed = p8;
+            f2.gate = ada + kE; f2.ldg = ldada; f2.gmap = amap; f2.R = w.x; f2.ldr = kE; f2.M = M; f2.N = kE; f2.K = 4 * kE; f2.a_packed = p8; f2.a_exp = E.ffn;
             const LnArgs nn = ln_args(l + 1, 0);               // next block's first norm, or the head's after the last block
             have_ln = gemm(m, f2, s, &nn);
             if (l == 0) tap_copy(m, TAP_BLK0_OUT, off, w.x, pn, kE, B, s);        // output of attn_blocks[0] (app/transformer.py:43)
@@ -875,11 +914,11 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s, int n_reencode = -1) 
     const int H = c.vae_hidden;
     roctxRangePushA("artalk.vae.decode");               // K15
     launch_dec_input(w.prev_fdec, w.fhat, w.bits, m->dec_pos, w.dec_x, B, s);
-    audit(m, "vae.decoder.input(fp32 A)", w.dec_x, B * 200, c.code_dim, c.code_dim, false, s);
-    linear(m, w.dec_x, c.code_dim, m->dec.in_w, m->dec.in_b, w.vh, H, B * 200, H, c.code_dim, ACT_LEAKY02, nullptr, s);
+    audit(m, "vae.decoder.input(fp32 A)", -1, nullptr, w.dec_x, B * 200, c.code_dim, c.code_dim, false, s, &ex.vae_dec_in);
+    linear(m, w.dec_x, c.code_dim, m->dec.in_w, m->dec.in_b, w.vh, H, B * 200, H, c.code_dim, ACT_LEAKY02, nullptr, s, 0, nullptr, ex.vae_dec_in);
     run_vae_stack(m, m->dec, B, 200, 100, s);
-    audit(m, "vae.decoder.output_head(fp32 A)", w.vh, B * 200, H, H, false, s);
-    linear(m, w.vh, H, m->dec.out_w, m->dec.out_b, w.dec_out, c.motion_dim, B * 200, c.motion_dim, H, ACT_NONE, nullptr, s);
+    audit(m, "vae.decoder.output_head(fp32 A)", -1, nullptr, w.vh, B * 200, H, H, false, s, &ex.vae_dec_head);
+    linear(m, w.vh, H, m->dec.out_w, m->dec.out_b, w.dec_out, c.motion_dim, B * 200, c.motion_dim, H, ACT_NONE, nullptr, s, 0, nullptr, ex.vae_dec_head);
     tap_copy(m, TAP_DEC_OUT, 0, w.dec_out, 200, c.motion_dim, B, s);               // dec_out before unnorm_with_stats (bitwise_vae.py:111)
     launch_dec_finish(w.dec_out, m->vae_mean, m->vae_std, m->enc_pos, w.motion_chunk, 100L * c.motion_dim, 0, w.enc_in, B, s, w.status);
     roctxRangePop();
@@ -1354,10 +1393,64 @@ int artalk_set_audit(artalk_model* m, int enable) {
     if (enable) {
         HIPCHK(m, hipDeviceSynchronize());
         HIPCHK(m, hipMemset(m->audit_vals, 0, kAuditSlots * sizeof(unsigned int)));
-        m->audit_names.clear(); m->audit_index.clear();
+        m->audit_names.clear(); m->audit_index.clear(); m->audit_exp.clear();
     }
     m->audit = enable != 0;
     return ARTALK_OK;
+}
+// Per-site operand scales of the f16x3 format from the audit's maxima (SiteExps): after artalk_infer calls with the audit on - in EXACT-F32
+// mode, where no site can overflow on the way to a later one - every site whose max |x| * 2^e * headroom exceeds fp16's 65504 gets the
+// largest exponent e (<= the default 4, >= -8) that fits.  Exponents only go down (a later calibration on tamer inputs never undoes an
+// earlier one; artalk_reset_scales does).  Captured graphs and the initial-history cache are dropped when anything changed.
+// Returns the number of sites changed (>= 0), or a negative error: ARTALK_ESTATE without audit data, ARTALK_EINVAL for a non-finite
+// maximum (run the pass in f32 mode) or one that no exponent >= -8 can hold.
+int artalk_calibrate(artalk_model* m, float headroom) {
+    if (!m || !(headroom >= 1.0f)) return ARTALK_EINVAL;
+    if (!m->audit_vals || m->audit_names.empty()) { m->err = "artalk_calibrate: no audit data (artalk_set_audit(1), then artalk_infer in f32 mode)"; return ARTALK_ESTATE; }
+    (void)hipSetDevice(m->device);
+    if (hipDeviceSynchronize() != hipSuccess) return ARTALK_EHIP;
+    const int n = (int)m->audit_names.size();
+    std::vector<unsigned int> bits((size_t)n);
+    if (hipMemcpy(bits.data(), m->audit_vals, n * sizeof(unsigned int), hipMemcpyDeviceToHost) != hipSuccess) return ARTALK_EHIP;
+    int changed = 0;
+    for (int i = 0; i < n; ++i) {
+        int* ex = m->audit_exp[i];
+        if (!ex) continue;
+        float mx;
+        std::memcpy(&mx, &bits[i], sizeof(float));
+        if (!std::isfinite(mx)) { m->err = "artalk_calibrate: site " + m->audit_names[i] + " is not finite (calibrate in f32 mode)"; return ARTALK_EINVAL; }
+        if (mx <= 0.f) continue;
+        int e = *ex;
+        while (e > -8 && (double)mx * std::ldexp(1.0, e) * headroom > 65504.0) --e;
+        if ((double)mx * std::ldexp(1.0, e) > 65504.0) { m->err = "artalk_calibrate: site " + m->audit_names[i] + " exceeds every supported scale"; return ARTALK_EINVAL; }
+        if (e != *ex) { *ex = e; ++changed; }
+    }
+    if (changed) {
+        for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second.exec);      // the exponents are kernel arguments of the captured launches
+        m->graphs.clear();
+        m->init_hist[0].valid = m->init_hist[1].valid = false;
+    }
+    const int* p = reinterpret_cast<const int*>(&m->ex);
+    m->scales_changed = 0;
+    for (size_t i = 0; i < sizeof(SiteExps) / sizeof(int); ++i) m->scales_changed += p[i] != kActExp;
+    return changed;
+}
+int artalk_reset_scales(artalk_model* m) {
+    if (!m) return ARTALK_EINVAL;
+    (void)hipSetDevice(m->device); (void)hipDeviceSynchronize();
+    m->ex = SiteExps();
+    m->scales_changed = 0;
+    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second.exec);
+    m->graphs.clear();
+    m->init_hist[0].valid = m->init_hist[1].valid = false;
+    return ARTALK_OK;
+}
+// exps[i] = exponent of audit site i (the order of artalk_get_audit); returns the number written
+int artalk_get_scales(artalk_model* m, int* exps, int max_n) {
+    if (!m || !exps || max_n <= 0) return ARTALK_EINVAL;
+    const int n = std::min<int>((int)m->audit_names.size(), max_n);
+    for (int i = 0; i < n; ++i) exps[i] = m->audit_exp[i] ? *m->audit_exp[i] : kActExp;
+    return n;
 }
 int artalk_get_audit(artalk_model* m, char* names_buf, int buf_len, float* values, int max_n) {
     if (!m || !names_buf || !values || buf_len <= 0 || max_n <= 0) return ARTALK_EINVAL;
@@ -1487,7 +1580,7 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
     auto ada_table = [&](int64_t j) {
         roctxRangePushA("artalk.ar.adaln_table");
         linear(m, w.silu_cond + (long)base[j] * kNTok * kCond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, Bj[j] * kNTok, m->ada_n, kCond,
-               ACT_NONE, nullptr, s, m->precision == 1 ? LF_A_P8 : 0);
+               ACT_NONE, nullptr, s, m->precision == 1 ? LF_A_P8 : 0, nullptr, m->ex.silu_cond);
         roctxRangePop();
     };
     for (int64_t j = 0; j < maxch; ++j) {
@@ -1603,7 +1696,7 @@ int artalk_stream_chunk(artalk_model* m, const float* audio_dev, int64_t chunk_s
     ProfilingOff quiet(m);      // restored on every exit path
     for (int c0 = 0; c0 < B; c0 += w.G) run_wav2vec(m, audio_dev, c0, std::min(w.G, B - c0), nullptr, s);
     linear(m, w.silu_cond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, B * kNTok, m->ada_n, kCond, ACT_NONE, nullptr, s,
-           m->precision == 1 ? LF_A_P8 : 0);
+           m->precision == 1 ? LF_A_P8 : 0, nullptr, m->ex.silu_cond);
     if (m->use_graphs) {
         if (int brc = run_chunk_body_graphs(m, B, s)) return brc;
     } else {

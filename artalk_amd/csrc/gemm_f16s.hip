@@ -45,12 +45,12 @@ __device__ __forceinline__ int p8_lds_offset(int c) { return (c & 1) * 64 + (c >
 // [8 x f16 hi][8 x f16 lo] (same size as the 8 floats it replaces, so a P8 matrix keeps the fp32 matrix's pitch and
 // indexing).  A 16-byte chunk of a P8 row is therefore directly an MFMA operand fragment (k = 8h .. 8h+7).
 __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, unsigned int* __restrict__ out, long n, float scale,
-                                                         int* __restrict__ status) {
+                                                         int* __restrict__ status, unsigned int maxbits) {
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long)gridDim.x * 2048) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(w + i), b = *reinterpret_cast<const f32x4*>(w + i + 4);
-        if (status) {      // activations only (scale = kActScale): range guard of the P8 format
-            p8_guard(status, a[0], a[1], a[2], a[3]);
-            p8_guard(status, b[0], b[1], b[2], b[3]);
+        if (status) {      // activations only (scale = 2^p8_exp): range guard of the P8 format
+            p8_guard(status, a[0], a[1], a[2], a[3], maxbits);
+            p8_guard(status, b[0], b[1], b[2], b[3], maxbits);
         }
         u32x2 h0, l0, h1, l1;
         split_f32x4(a, scale, h0, l0);
@@ -60,11 +60,11 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
         *reinterpret_cast<u32x4*>(out + i + 4) = lo;
     }
 }
-void launch_pack_split(const float* w, unsigned int* out, long n, bool is_weight, hipStream_t s, int* status) {
+void launch_pack_split(const float* w, unsigned int* out, long n, bool is_weight, hipStream_t s, int* status, int p8_exp) {
     if (n <= 0) return;
     if (is_weight) status = nullptr;
     const long blocks = (n / 8 + 255) / 256;   // n % 8 == 0 (every packed tensor has an inner dimension that is a multiple of 32)
-    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, w, out, n, is_weight ? kWScale : kActScale, status);
+    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, w, out, n, is_weight ? kWScale : p8_scale_of(p8_exp), status, p8_maxbits_of(p8_exp));
 }
 
 // AMODE 1: grouped positional-conv window gather (see gemm_f32.hip), grid.z = group, fp32 A only.
@@ -138,9 +138,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
                 u32x2 hi, lo;
                 {
                     const f32x4 av = __builtin_bit_cast(f32x4, ra[i]);
-                    p8_guard(g.status, av[0], av[1], av[2], av[3]);
+                    p8_guard(g.status, av[0], av[1], av[2], av[3], p8_maxbits_of(g.a_exp));
                 }
-                split_f32x4(__builtin_bit_cast(f32x4, ra[i]), kActScale, hi, lo);
+                split_f32x4(__builtin_bit_cast(f32x4, ra[i]), p8_scale_of(g.a_exp), hi, lo);
                 *reinterpret_cast<u32x2*>(p + lc4 * 2) = hi;
                 *reinterpret_cast<u32x2*>(p + lc4 * 2 + 64) = lo;
             }
@@ -207,13 +207,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16s_kernel(const GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] *= p8_out_scale_of(g.a_exp);
                 partial_tile32(g, P, m0 + wm * (BM / WM) + i * 32 + r, n0 + wn * (BN / WN) + j * 32, h, acc[i][j]);
             }
         return;
     }
     const EpiCtx epi = make_epi(g, g.bias ? g.bias + z * g.sBias : nullptr, g.C + z * g.sC, g.R ? g.R + z * g.sR : nullptr);
-    epilogue_tiles<true, true, TM, TN>(g, epi, m0 + wm * (BM / WM) + r, n0 + wn * (BN / WN), h, acc, kOutScale);
+    epilogue_tiles<true, true, TM, TN>(g, epi, m0 + wm * (BM / WM) + r, n0 + wn * (BN / WN), h, acc, p8_out_scale_of(g.a_exp));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -424,13 +424,13 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_256_kernel(const GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] *= p8_out_scale_of(g.a_exp);
         epilogue_wave_lds<2, 2>(g, epi, lds, m0 + wm * 128, n0 + wn * 64, lane, lo2);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         epilogue_wave_lds<2, 2>(g, epi, lds, m0 + wm * 128 + 64, n0 + wn * 64, lane, hi2);
     } else {
-        epilogue_tiles<true, false, 4, 2>(g, epi, m0 + wm * 128 + r, n0 + wn * 64, h, acc, kOutScale);
+        epilogue_tiles<true, false, 4, 2>(g, epi, m0 + wm * 128 + r, n0 + wn * 64, h, acc, p8_out_scale_of(g.a_exp));
     }
     if constexpr (ABL == 6) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_big_kernel(const GemmArgs g) {
                 f32x4 b = {0.f, 0.f, 0.f, 0.f};
                 if (g.bias) b = *reinterpret_cast<const f32x4*>(bslot + (j * 32 + 8 * q + 4 * h) * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = acc[i][j][4 * q + e] * kOutScale + b[e];
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = acc[i][j][4 * q + e] * p8_out_scale_of(g.a_exp) + b[e];
             }
             if constexpr (has_res) {
 #pragma unroll
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_2wgp_kernel(const GemmArgs g) 
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) keep[i][j][4 * q + e] = acc[i][j][4 * q + e] * kOutScale + b[e];
+                        for (int e = 0; e < 4; ++e) keep[i][j][4 * q + e] = acc[i][j][4 * q + e] * p8_out_scale_of(g.a_exp) + b[e];
                 }
             if ((can_defer || defer_res) && full) {
                 pending = true; pending_res = defer_res; pm0 = m0; pn0 = n0; pC = epi.C;
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_mid_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
+            for (int e = 0; e < 16; ++e) acc[i][j][e] *= p8_out_scale_of(g.a_exp);
     if (g.splitk > 1) {      // raw sums; splitk_reduce[_ln768]_kernel finishes them
         float* __restrict__ P = g.partial + (long)blockIdx.y * g.M * g.N;
 #pragma unroll
@@ -1277,6 +1277,226 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_mid_kernel(const GemmArgs g) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Ping-pong kernel for the one- and two-round launches of the AR / VAE body (round 5): BM x BN tile, ONE workgroup of 8
+// waves (WMW x WNW, wave tile 32 TMW x 32 TNW) per CU.  What differs from gemm_p8_mid_kernel:
+//   * the two waves of a SIMD (waves w and w + 4: groups X = 0-3, Y = 4-7) run the SAME program one phase apart: a K step of a wave is
+//     a LOAD phase L(k) - the DMA pieces of stage k + S - 1 first, then ALL fragments of stage k into registers (ds_read_b128 x
+//     4 (TMW + TNW)) - and a COMPUTE phase C(k) - its 6 TMW TNW MFMAs back to back out of registers.  X runs L(k) while Y runs C(k - 1),
+//     then X runs C(k) while Y runs L(k): one wave's matrix work sits under the other's fragment reads, address arithmetic, DMA issue
+//     and waits (in the mid-grid kernel both waves of a SIMD reach their reads, their waits and the barrier together:
+//     0.62 - 0.7 us per K step where the MFMAs need 0.37);
+//   * a stage lives in registers one phase after it was read, so its LDS buffer is free again TWO phases after it landed: a ring of 3
+//     stages keeps two K steps in flight (the in-phase structure reads a stage over a whole step and needs 4 buffers for that), which
+//     is what makes a 256 x 128 tile (48 KB per stage: 0.75 of the operand bytes per flop of 128 x 128) fit the 160 KB of LDS;
+//   * DMA pieces are buffer loads to LDS (descriptor in SGPRs, 32-bit lane offsets, hardware range check instead of a row clamp).
+// Synchronisation per K step: ONE mandatory barrier O_k (behind a counted vmcnt wait: stage k + 1 has landed for every wave, every wave
+// has read stage k) and, with BAR2, a second one E_k between the two phases of a step (keeps the groups exactly one phase apart;
+// without it they pair up by themselves).  Accumulation order per output element is that of every other split kernel.
+template <int BM, int BN, int WMW, int WNW, int STAGES, int BAR2, int TAG>
+__global__ __launch_bounds__(512, 1) void gemm_p8_pp_kernel(const GemmArgs g) {
+    constexpr int BK = 32;
+    static_assert(WMW * WNW == 8, "8 waves");
+    constexpr int TMW = BM / WMW / 32, TNW = BN / WNW / 32;
+    constexpr int APIECES = BM / 64, WPIECES = BN / 64, NP = APIECES + WPIECES;      // 1-KiB DMA pieces per wave per stage
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static_assert(STAGES >= 3 && STAGES * STAGE_BYTES <= 160 * 1024, "LDS");
+    static_assert((STAGES - 1) * NP <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p8[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool grp_y = wave >= 4;      // (wave-uniform) the half of the workgroup that runs one phase behind
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    int tm, tn;
+    {   // XCD-contiguous, grouped column-major tile order (as gemm_p8_mid_kernel)
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GM = (BM >= 256) ? 2 : 4;
+        const int width = GM * tiles_n;
+        const int group = idx / width, first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        const int in_g = idx - group * width;
+        tn = in_g / gsz;
+        tm = first_m + (in_g - tn * gsz);
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk_all = g.K / BK, kt0 = (int)((long)nk_all * blockIdx.y / g.splitk);
+    const int nk = (int)((long)nk_all * (blockIdx.y + 1) / g.splitk) - kt0;      // K tiles [kt0, kt0 + nk)
+
+    // ---- DMA: piece = 8 rows x 128 B; wave w owns A pieces w * APIECES .. and W pieces w * WPIECES ..; lane = (row in piece, chunk) ----
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0,
+                                                                            (int)(((unsigned)(g.M - 1) * (unsigned)g.lda + (unsigned)g.K) * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(g.Wp), 0,
+                                                                            (int)(((unsigned)(g.N - 1) * (unsigned)g.ldw + (unsigned)g.K) * 4u), 0x00020000);
+    unsigned poff[NP];      // byte offset of this lane's 16 bytes of piece q at K tile 0 (rows beyond the operand: dropped by the range check -> zeros)
+#pragma unroll
+    for (int q = 0; q < APIECES; ++q) {
+        const int ra = (wave * APIECES + q) * 8 + prow;
+        poff[q] = (unsigned)(m0 + ra) * (unsigned)(g.lda * 4) + (unsigned)((pchunk ^ ((ra >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int q = 0; q < WPIECES; ++q) {
+        const int rw = (wave * WPIECES + q) * 8 + prow;
+        poff[APIECES + q] = (unsigned)(n0 + rw) * (unsigned)(g.ldw * 4) + (unsigned)((pchunk ^ ((rw >> 1) & 7)) << 4);
+    }
+    auto issue_stage = [&](int kt, int buf) __attribute__((always_inline)) {
+        unsigned char* base = smem_p8 + buf * STAGE_BYTES;
+        const int koff = (kt0 + kt) * (BK * 4);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            unsigned char* dst = q < APIECES ? base + (wave * APIECES + q) * 1024 : base + BM * 128 + (wave * WPIECES + q - APIECES) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(q < APIECES ? a_rsrc : w_rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)poff[q], koff, 0, 0);
+        }
+    };
+
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int r = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_p8;
+    unsigned a_off[2][2], w_off[2][2];      // [kb][hi / lo]; further 32-row tiles are + 4096 B (same swizzle key: an immediate)
+    {
+        const int arow = wm * (32 * TMW) + r, wrow = wn * (32 * TNW) + r;
+        const int akey = (arow >> 1) & 7, wkey = (wrow >> 1) & 7;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int lo = 0; lo < 2; ++lo) {
+                const int c = (kb * 2 + h) * 2 + lo;
+                a_off[kb][lo] = lds0 + arow * 128 + ((c ^ akey) << 4);
+                w_off[kb][lo] = lds0 + BM * 128 + wrow * 128 + ((c ^ wkey) << 4);
+            }
+    }
+
+    f32x16 acc[TMW][TNW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f16x8 ah[2][TMW], al[2][TMW], bh[2][TNW], bl[2][TNW];      // all fragments of one K step: [kb][tile]
+    constexpr int NRD_KB = 2 * (TMW + TNW);                       // ds_read_b128 per k block
+    static_assert(2 * NRD_KB <= 15 || true, "");
+    // LOAD phase of K step k: the pieces of stage k + S - 1 first (a Y wave's pieces have three phases to land, an X wave's four), then
+    // every fragment of stage k, k block 0 first
+    // (timing builds, results wrong: PP_ABL_NOMFMA one MFMA of a phase's 6 TMW TNW, PP_ABL_NODMA no DMA behind the prologue, PP_ABL_NOLDS
+    // fragments read in the first K step only; tools/pp_ablation.sh)
+    auto load_phase = [&](int k) __attribute__((always_inline)) {
+#ifndef PP_ABL_NODMA
+        if (k >= 1 && k + STAGES - 1 < nk) issue_stage(k + STAGES - 1, (k - 1) % STAGES);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef PP_ABL_NOLDS
+        if (k > 0) return;
+#endif
+        const unsigned sb = (unsigned)((k % STAGES) * STAGE_BYTES);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const unsigned ahp = a_off[kb][0] + sb, alp = a_off[kb][1] + sb, whp = w_off[kb][0] + sb, wlp = w_off[kb][1] + sb;
+            static_for<0, TNW>([&](auto j_tag) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_tag)::value;
+                bh[kb][j] = lds_read128<j * 4096>(whp);
+                bl[kb][j] = lds_read128<j * 4096>(wlp);
+            });
+            static_for<0, TMW>([&](auto i_tag) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_tag)::value;
+                ah[kb][i] = lds_read128<i * 4096>(ahp);
+                al[kb][i] = lds_read128<i * 4096>(alp);
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // COMPUTE phase: k block 0 as soon as its fragments are in (the k block 1 reads fly on), then k block 1
+    auto compute_phase = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            __builtin_amdgcn_sched_barrier(0);      // (the k block 0 MFMAs stay in front of the k block 1 wait)
+            if (kb == 0) wait_lgkmcnt<(NRD_KB <= 15 ? NRD_KB : 15)>(); else wait_lgkmcnt<0>();
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j) {      // weight fragment = A operand: C^T, see epilogue_tile32
+#ifdef PP_ABL_NOMFMA
+                        if (t + i + j + kb > 0) continue;
+#endif
+                        if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], ah[kb][i], acc[i][j], 0, 0, 0);
+                        else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kb][j], ah[kb][i], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kb][j], al[kb][i], acc[i][j], 0, 0, 0);
+                    }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    {
+        const int pro = min(STAGES, nk);
+        for (int st = 0; st < pro; ++st) issue_stage(st, st);
+        wait_vmcnt_units<NP>(pro - 1);      // stage 0 has landed for this wave ...
+        __builtin_amdgcn_s_barrier();       // ... and for every wave
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ONE program for both groups (no divergent path around the fragment and accumulator registers: the asm reads' results may not cross
+    // a control-flow join before their wait): L(k) | C(k) per K step; what differs is where a group's barriers sit.
+    //   BAR2 = 0: X has its barrier O_k behind C(k), Y behind L(k) - so Y runs C(k - 1) | L(k) between two barriers while X runs L(k) | C(k);
+    //   BAR2 = 1: a barrier behind every phase; Y takes one extra barrier first (it starts one phase late), X one extra at the end.
+    // O_k (X: behind C(k), Y: behind L(k)) is taken behind the wait for this wave's pieces of stage k + 1: at most the stages issued
+    // behind it, k + 2 .. min(k + S - 1, nk - 1), stay in flight.  A load phase's reads have returned before its barrier, so that
+    // nobody's DMA can overwrite a buffer under a read in flight.
+    if (BAR2 && grp_y) __builtin_amdgcn_s_barrier();
+#pragma nounroll
+    for (int k = 0; k < nk; ++k) {
+        const bool more = k + 1 < nk;
+        const int units = min(STAGES - 2, nk - 2 - k);
+        load_phase(k);
+        if (BAR2 || (grp_y && more)) {
+            if (grp_y) {
+                wait_lgkmcnt<0>();
+                if (more) wait_vmcnt_units<NP>(units);
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        compute_phase();
+        if (BAR2 || (!grp_y && more)) {
+            if (!grp_y && more) wait_vmcnt_units<NP>(units);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (BAR2 && !grp_y) __builtin_amdgcn_s_barrier();
+
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] *= p8_out_scale_of(g.a_exp);
+    if (g.splitk > 1) {      // raw sums; splitk_reduce[_ln768]_kernel finishes them
+        float* __restrict__ P = g.partial + (long)blockIdx.y * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) partial_tile32(g, P, m0 + wm * (32 * TMW) + i * 32 + r, n0 + wn * (32 * TNW) + j * 32, h, acc[i][j]);
+        return;
+    }
+    const EpiCtx epi = make_epi(g, g.bias, g.C, g.R);
+    if (epi.vec) {      // coalesced: transpose through this wave's slice of the (now idle) stage ring
+        __builtin_amdgcn_s_barrier();      // every wave has read its last fragments (no DMA is in flight: every stage was waited for)
+        constexpr int SLICE = 32 * TMW * (32 * TNW + 4);
+        static_assert(8 * SLICE * 4 <= STAGES * STAGE_BYTES, "epilogue LDS");
+        epilogue_wave_lds<TMW, TNW, true>(g, epi, reinterpret_cast<float*>(smem_p8) + wave * SLICE, m0 + wm * (32 * TMW), n0 + wn * (32 * TNW), lane, acc);
+    } else {
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) epilogue_tile32<true, true>(g, epi, m0 + wm * (32 * TMW) + i * 32 + r, n0 + wn * (32 * TNW) + j * 32, h, acc[i][j]);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Small-grid variant for the AR/VAE scale steps (M = clips x 1..100 tokens): these launches are bound by the latency of ONE
@@ -1447,7 +1667,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p8_sm_kernel(const GemmArgs g) { 
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] *= kOutScale;
+            for (int e = 0; e < 16; ++e) acc[i][j][e] *= p8_out_scale_of(g.a_exp);
     if (g.splitk > 1) {
         float* __restrict__ P = g.partial + (long)blockIdx.y * g.M * g.N;
 #pragma unroll
@@ -1519,12 +1739,12 @@ __global__ __launch_bounds__(512) void posconv_p8_kernel(const GemmArgs g, int T
             const float* xp = g.A + (row0 + ts) * g.lda + grp * CG + g8 * 8;
             a = *reinterpret_cast<const f32x4*>(xp);
             b = *reinterpret_cast<const f32x4*>(xp + 4);
-            p8_guard(g.status, a[0], a[1], a[2], a[3]);
-            p8_guard(g.status, b[0], b[1], b[2], b[3]);
+            p8_guard(g.status, a[0], a[1], a[2], a[3], p8_maxbits_of(g.a_exp));
+            p8_guard(g.status, b[0], b[1], b[2], b[3], p8_maxbits_of(g.a_exp));
         }
         u32x2 h0, l0, h1, l1;
-        split_f32x4(a, kActScale, h0, l0);
-        split_f32x4(b, kActScale, h1, l1);
+        split_f32x4(a, p8_scale_of(g.a_exp), h0, l0);
+        split_f32x4(b, p8_scale_of(g.a_exp), h1, l1);
         const u32x4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
         unsigned char* rowp = win + w * PC_PITCH + g8 * 32;
         *reinterpret_cast<u32x4*>(rowp) = hi;
@@ -1638,7 +1858,7 @@ __global__ __launch_bounds__(512) void posconv_p8_kernel(const GemmArgs g, int T
 #pragma nounroll
     for (int i = 0; i < 2; ++i) {                            // one copy of the epilogue code (common.h, epilogue_tiles)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[0][e] *= kOutScale;
+        for (int e = 0; e < 16; ++e) acc[0][e] *= p8_out_scale_of(g.a_exp);
         const int t = wm * 64 + 32 * i + r;                  // frame inside the chunk; rows >= Ts belong to nobody
         const int row = t < Ts ? (int)(row0 + t) : g.M;
         epilogue_tile32(g, epi, row, grp * CG + wn * 32, h, acc[0]);
@@ -1682,9 +1902,30 @@ static void launch_p8_mid(const GemmArgs& g, hipStream_t s) {
     if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_mid_kernel<STAGES, 1>), dim3(tiles, g.splitk), dim3(512), STAGES * 256 * 128, s, g);
     else hipLaunchKernelGGL((gemm_p8_mid_kernel<STAGES, 0>), dim3(tiles, g.splitk), dim3(512), STAGES * 256 * 128, s, g);
 }
+template <int BM, int BN, int WMW, int WNW, int STAGES, int BAR2>
+static void launch_p8_pp(const GemmArgs& g, hipStream_t s) {
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    gemm_p8_prepare();
+    const size_t lds = STAGES * (BM + BN) * 128;
+    if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_pp_kernel<BM, BN, WMW, WNW, STAGES, BAR2, 1>), dim3(tiles, g.splitk), dim3(512), lds, s, g);
+    else hipLaunchKernelGGL((gemm_p8_pp_kernel<BM, BN, WMW, WNW, STAGES, BAR2, 0>), dim3(tiles, g.splitk), dim3(512), lds, s, g);
+}
+// what gemm_p8_pp_kernel's 32-bit DMA offsets need: operands below 4 GiB
+bool gemm_p8_pp_ok(const GemmArgs& g) {
+    return (double)g.M * g.lda * 4.0 < 4294967296.0 && (double)g.N * g.ldw * 4.0 < 4294967296.0;
+}
 void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return;
-    switch (g.force_cfg) {
+    int cfg = g.force_cfg;
+    if (cfg >= 30 && cfg <= 35 && !gemm_p8_pp_ok(g)) cfg = 28;
+    switch (cfg) {
+        // ping-pong kernel (round 5): 30 / 31 = 256 x 128 tile, 3 stages, one / two barriers per K step; 32 / 33 = 128 x 128, 4 stages; 34 / 35 = 128 x 256, 3 stages
+        case 30: launch_p8_pp<256, 128, 4, 2, 3, 0>(g, s); break;
+        case 31: launch_p8_pp<256, 128, 4, 2, 3, 1>(g, s); break;
+        case 32: launch_p8_pp<128, 128, 2, 4, 4, 0>(g, s); break;
+        case 33: launch_p8_pp<128, 128, 2, 4, 4, 1>(g, s); break;
+        case 34: launch_p8_pp<128, 256, 2, 4, 3, 0>(g, s); break;
+        case 35: launch_p8_pp<128, 256, 2, 4, 3, 1>(g, s); break;
         case 28: launch_p8_mid<4>(g, s); break;
         case 29: launch_p8_mid<5>(g, s); break;      // (experiment: the whole 160 KiB of LDS as a ring of 5 stages, four K tiles in flight)
         case 23: launch_p8_sm_cfg<64, 64, 8>(g, s); break;
@@ -1719,6 +1960,16 @@ void gemm_p8_prepare() {      // more than the default 64 KB of dynamic LDS (out
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_mid_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_mid_kernel<5, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_mid_kernel<5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128);
+    {
+        const void* pp[] = {reinterpret_cast<const void*>(&gemm_p8_pp_kernel<256, 128, 4, 2, 3, 0, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<256, 128, 4, 2, 3, 0, 1>),
+                            reinterpret_cast<const void*>(&gemm_p8_pp_kernel<256, 128, 4, 2, 3, 1, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<256, 128, 4, 2, 3, 1, 1>),
+                            reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 256, 2, 4, 3, 0, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 256, 2, 4, 3, 0, 1>),
+                            reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 256, 2, 4, 3, 1, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 256, 2, 4, 3, 1, 1>)};
+        for (const void* f : pp) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 384 * 128);
+        const void* pq[] = {reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 128, 2, 4, 4, 0, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 128, 2, 4, 4, 0, 1>),
+                            reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 128, 2, 4, 4, 1, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 128, 2, 4, 4, 1, 1>)};
+        for (const void* f : pq) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128);
+    }
     done[dev] = true;
 }
 // Production kernels: force_cfg 7 / 12 = gemm_p8_big_kernel with 256 x 256 / 320 x 256 tiles (persistent, one workgroup per CU),

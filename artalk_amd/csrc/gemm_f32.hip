@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_ln768_kernel(const GemmArgs
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * (scv[i][e] + 1.0f) + shv[i][e];
-        if (ln.out_p8) store_p8x4_pair(y, c, o[0], o[1], o[2], o[3], ln.status);
+        if (ln.out_p8) store_p8x4_pair(y, c, o[0], o[1], o[2], o[3], ln.status, ln.p8_exp);
         else { const f32x4 w = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4*>(y + c) = w; }
     }
 }

@@ -21,6 +21,7 @@ static inline RowMap rowmap(int rows_per_batch, int batch_stride_rows, int row_o
 }
 
 enum Act { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_TANH = 2, ACT_LEAKY02 = 3 };
+constexpr int kActExp = 4;      // default site exponent of the P8 split format: activations scaled by 2^4 (common.h)
 
 // C[cmap(m), n] = R[cmap(m), n] + gate[gmap(m), n] * act(sum_k A[m,k] * W[n,k] + bias[n])
 // A is [M,K] (row stride lda), W is [N,K] row-major (torch nn.Linear layout).  K % 32 == 0.
@@ -30,6 +31,9 @@ struct GemmArgs {
     const unsigned int* Wp = nullptr;   // optional copy of W in the P8 split format (common.h), same ld: f16x3 split path
     int c_p8 = 0;                        // 1: write C in the P8 split format (the consumer is a split GEMM); every split-GEMM epilogue and the split-K reduce
     int a_packed = 0;                    // 1: A is already in the P8 split format (written so by its producer kernel), f16x3 path only
+    // site exponents of the P8 format (common.h): A was written (a_packed) or is split while staging (fp32 A) with scale 2^a_exp; a P8
+    // result (c_p8, c2) is written with 2^c_exp.  kActExp (16) unless the model's calibration lowered a site with outlier activations.
+    int a_exp = 4, c_exp = 4;
     int exact = 0;                       // 1: decision-critical GEMM (logit / code heads), always on the fp32 MFMA path
     const float* bias = nullptr;
     float* C = nullptr; long ldc = 0; RowMap cmap = {INT_MAX, 0, 0};
@@ -65,7 +69,7 @@ bool splitk_reduce_ln_eligible(const GemmArgs& g, const LnArgs& ln);
 void launch_splitk_reduce_ln(const GemmArgs& g, const LnArgs& ln, hipStream_t s);
 int gemm_tile_count(const GemmArgs& g, bool f16s);             // output tiles of the configuration launch_gemm[_f16s] would pick
 // fp32-accurate GEMM on the fp16 matrix cores by operand splitting (gemm_f16s.hip)
-void launch_pack_split(const float* w, unsigned int* out, long n, bool is_weight, hipStream_t s, int* status = nullptr);
+void launch_pack_split(const float* w, unsigned int* out, long n, bool is_weight, hipStream_t s, int* status = nullptr, int p8_exp = kActExp);
 bool gemm_f16s_eligible(const GemmArgs& g);
 int gemm_f16s_config(const GemmArgs& g);     // register-staged kernel: 0: 128x128, 1: 64x64
 void launch_gemm_f16s(const GemmArgs& g, hipStream_t s);
@@ -91,6 +95,7 @@ struct LnArgs {
     long ldm = 0; RowMap mmap = {INT_MAX, 0, 0};
     int M = 0, D = 0; float eps = 1e-5f; int act = ACT_NONE;
     int out_p8 = 0;   // 1: write Y in the P8 split format (consumer is a split GEMM); same row pitch as fp32
+    int p8_exp = 4;   // out_p8: site exponent (scale 2^p8_exp, common.h)
     int* status = nullptr;   // out_p8: range guard (see GemmArgs::status)
     // rows r with r % junk_period >= junk_from are layout padding (the per-chunk row stride of the wav2vec2 buffers exceeds the
     // valid frames; their input is whatever an earlier launch left there and no valid row ever reads them): they are stored as
@@ -111,6 +116,7 @@ struct AttnArgs {
     int out_p8 = 0;                                  // 1: write O in the P8 split format
     int split16 = 0;                                 // 1: fp16 operand-split MFMAs (f16x3 mode), 0: exact fp32 MFMAs
     int qkv_p8 = 0;                                  // 1 (with split16, no l2norm): Q, K, V rows are in the P8 split format (written so by the qkv GEMM)
+    int qkv_exp = 4, o_exp = 4;                      // site exponents of the P8 format: Q / K / V rows (qkv_p8), O rows (out_p8)
     int* status = nullptr;                           // out_p8: range guard (see GemmArgs::status)
     int cus = 0;                                     // compute units of the model's partition (0 = the whole device): grid of the persistent kernel
     // short-query kernel, Lq <= 16: the q | k | v rows of the NEW tokens (the last Lq keys) are still split-K slabs [n_slabs][B * Lq][slab_ld]
@@ -126,10 +132,10 @@ void attention_prepare();      // one-time kernel attributes (call once per proc
 void launch_audio_normalize(const float* audio, const long* src_off, float* xnorm, int n_chunks, int n, hipStream_t s);
 // conv0 (Cin=1,k=10,s=5) + bias + LN(512, affine) + GELU(erf): xnorm [C, n] -> Y rows c*row_stride + t, t < T
 void launch_conv0(const float* xnorm, int n, const float* w /*[512,10]*/, const float* bias, const float* lnw,
-                  const float* lnb, float* Y, int n_chunks, int T, int row_stride, hipStream_t s, int out_p8 = 0, int* status = nullptr);
+                  const float* lnb, float* Y, int n_chunks, int T, int row_stride, hipStream_t s, int out_p8 = 0, int* status = nullptr, int p8_exp = kActExp);
 // multi-scale adaptive average pooling 199 -> {1,5,25,50,100} followed by SiLU: X rows c*x_tstride + t -> Y rows c*181 + tok
 void launch_pool_silu(const float* X, int x_tstride, int T, float* Y, int n_chunks, const int* patch_nums, int n_lvls,
-                      int D, hipStream_t s, int out_p8 = 0, int* status = nullptr);
+                      int D, hipStream_t s, int out_p8 = 0, int* status = nullptr, int p8_exp = kActExp);
 
 // ---- AR / VAE glue ----
 // level p: logits [B*pn, 64] -> bits[b, off..off+pn, 32]; fhat[b] += up(h_p); nextfeat[b, :pn[p+1], 32] = area(fhat) (p < 4)
@@ -172,9 +178,9 @@ void launch_flame_pose(const float* pose, float* rot, float* feat, int T, int ld
 void launch_flame_joints(const float* vs, const float* jreg, float* J, int T, int V, hipStream_t s);
 void launch_flame_skin(const float* vposed, const float* rot, const float* J, const int* parents, const float* weights, float* out,
                        int T, int V, float scale, hipStream_t s);
-// headroom audit: *slot = max(*slot, bits of max |x| * 16) over rows x cols (cols % 8 == 0) of a P8 (is_p8) or fp32 buffer
+// headroom audit: *slot = max(*slot, bits of max |x|) over rows x cols (cols % 8 == 0) of a P8 (is_p8: written with scale 2^p8_exp) or fp32 buffer
 void launch_absmax(const float* buf, int rows, int cols, long ld, int is_p8, unsigned int* slot, hipStream_t s, int junk_period = 0,
-                   int junk_from = 0);
+                   int junk_from = 0, int p8_exp = kActExp);
 int init_ms_tables();    // uploads the (tiny) interpolation tables to the CURRENT device's __constant__ memory, once per device; 0 = ok
 
 }  // namespace artalk

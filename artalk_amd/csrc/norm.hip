@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
                 o[e] = junk ? 0.f : apply_act_rt(t, a.act);
             }
             if (VW == 4 && a.out_p8) {
-                store_p8x4_pair(y, c, o[0], o[1], o[2], o[3], status);      // c = 4 * (64 i + lane): adjacent lanes, adjacent runs
+                store_p8x4_pair(y, c, o[0], o[1], o[2], o[3], status, a.p8_exp);      // c = 4 * (64 i + lane): adjacent lanes, adjacent runs
             } else if (VW == 4) {
                 f32x4 t = {o[0], o[1], o[2], o[3]};
                 *reinterpret_cast<f32x4*>(y + c) = t;

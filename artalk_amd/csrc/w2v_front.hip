@@ -55,7 +55,7 @@ void launch_audio_normalize(const float* audio, const long* src_off, float* xnor
 // 20 bytes of audio in, 2 KiB out per frame: store-bandwidth bound.
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn, int n, const float* __restrict__ w,
                                                     const float* __restrict__ bias, const float* __restrict__ lnw,
-                                                    const float* __restrict__ lnb, float* __restrict__ Y, int T, int row_stride, int* __restrict__ status, int out_p8) {
+                                                    const float* __restrict__ lnb, float* __restrict__ Y, int T, int row_stride, int* __restrict__ status, int out_p8, int p8_exp) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.y;
     // channel pairs (2 jj, 2 jj + 1) of this lane in packed-fp32 registers: the 80 taps, the LayerNorm and the GELU polynomial run on
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
         if (out_p8) {
             // adjacent lanes own the two halves of one 8-element P8 group: they trade halves and issue ONE 16-byte store each
             // (2 store instructions per row and lane instead of 4)
-            store_p8x4_pair(y, lane * 4, o[0].x, o[0].y, o[1].x, o[1].y, status);
-            store_p8x4_pair(y, 256 + lane * 4, o[2].x, o[2].y, o[3].x, o[3].y, status);
+            store_p8x4_pair(y, lane * 4, o[0].x, o[0].y, o[1].x, o[1].y, status, p8_exp);
+            store_p8x4_pair(y, 256 + lane * 4, o[2].x, o[2].y, o[3].x, o[3].y, status, p8_exp);
         } else {
             f32x4 lo = {o[0].x, o[0].y, o[1].x, o[1].y}, hi = {o[2].x, o[2].y, o[3].x, o[3].y};
             *reinterpret_cast<f32x4*>(y + lane * 4) = lo;
@@ -115,16 +115,16 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
 }
 
 void launch_conv0(const float* xnorm, int n, const float* w, const float* bias, const float* lnw, const float* lnb,
-                  float* Y, int n_chunks, int T, int row_stride, hipStream_t s, int out_p8, int* status) {
+                  float* Y, int n_chunks, int T, int row_stride, hipStream_t s, int out_p8, int* status, int p8_exp) {
     if (n_chunks <= 0) return;
-    hipLaunchKernelGGL(conv0_kernel, dim3(128, n_chunks), dim3(256), 0, s, xnorm, n, w, bias, lnw, lnb, Y, T, row_stride, status, out_p8);
+    hipLaunchKernelGGL(conv0_kernel, dim3(128, n_chunks), dim3(256), 0, s, xnorm, n, w, bias, lnw, lnb, Y, T, row_stride, status, out_p8, p8_exp);
 }
 
 // ------------------------------------------------------------------------------------------------
 struct PoolLevels { int n; int pn[8]; };
 
 __global__ __launch_bounds__(256) void pool_silu_kernel(const float* __restrict__ X, int x_tstride, int T, float* __restrict__ Y,
-                                                        PoolLevels lv, int ntok, int D, int out_p8, int* __restrict__ status) {
+                                                        PoolLevels lv, int ntok, int D, int out_p8, int* __restrict__ status, int p8_exp) {
     const int tok = blockIdx.x, c = blockIdx.y;
     int p = 0, i = tok;
     while (i >= lv.pn[p]) { i -= lv.pn[p]; ++p; }
@@ -138,19 +138,19 @@ __global__ __launch_bounds__(256) void pool_silu_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = silu(s[e] / inv);
         float* yrow = Y + ((long)c * ntok + tok) * D;
-        if (out_p8) store_p8x4(yrow, d, o[0], o[1], o[2], o[3], status);
+        if (out_p8) store_p8x4(yrow, d, o[0], o[1], o[2], o[3], status, p8_exp);
         else *reinterpret_cast<f32x4*>(yrow + d) = o;
     }
 }
 
 void launch_pool_silu(const float* X, int x_tstride, int T, float* Y, int n_chunks, const int* patch_nums, int n_lvls, int D,
-                      hipStream_t s, int out_p8, int* status) {
+                      hipStream_t s, int out_p8, int* status, int p8_exp) {
     if (n_chunks <= 0) return;
     PoolLevels lv;
     lv.n = n_lvls;
     int ntok = 0;
     for (int i = 0; i < 8; ++i) { lv.pn[i] = i < n_lvls ? patch_nums[i] : 1 << 30; if (i < n_lvls) ntok += patch_nums[i]; }
-    hipLaunchKernelGGL(pool_silu_kernel, dim3(ntok, n_chunks), dim3(256), 0, s, X, x_tstride, T, Y, lv, ntok, D, out_p8, status);
+    hipLaunchKernelGGL(pool_silu_kernel, dim3(ntok, n_chunks), dim3(256), 0, s, X, x_tstride, T, Y, lv, ntok, D, out_p8, status, p8_exp);
 }
 
 }  // namespace artalk

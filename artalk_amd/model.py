@@ -63,7 +63,8 @@ class BitwiseARModel:
         # itself never synchronises).  False = fully asynchronous calls, the caller polls ``status(wait=False)`` when it likes.
         self.check_finite = True
         self._precision = "f16x3"   # default GEMM arithmetic (set_precision); applied when the weights are loaded
-        self._latched_f32 = False   # an f16x3 call left fp16's range once: the model stays in f32 mode from then on
+        self._latched_f32 = False   # an f16x3 call left fp16's range and recalibration did not cure it: the model stays in f32 mode from then on
+        self.auto_calibrate = True  # a tripped range guard first recalibrates the per-site operand scales on that batch (calibrate())
         self.style_cache_size = 64  # style conditions kept by style clip (set 0 to disable)
         self._style_cache = {}      # key -> (style tensor kept alive, (768,) condition on the device)
         self._stream = None      # dedicated HIP stream (hipGraph capture is not allowed on the legacy default stream)
@@ -178,6 +179,36 @@ class BitwiseARModel:
         if capi.lib().artalk_get_status_of(self._h, C.c_longlong(ticket), C.byref(f)) != capi.OK:
             raise RuntimeError("artalk status query failed: " + self._err())
         return int(f.value)
+
+    def calibrate(self, audios, style_motions=None, headroom: float = 4.0) -> int:
+        """Per-site operand scales of the f16x3 format from these clips (``artalk_calibrate``): one audit pass in exact-f32 mode
+        (nothing can overflow there), then every site whose ``max|x| * scale * headroom`` would leave fp16's range gets the largest
+        power-of-two scale that fits - only those sites change.  Returns the number of sites changed.  ``inference_batch`` calls this
+        by itself, once, when a call trips the range guard; a serving setup calls it after ``load_state_dict`` with representative
+        clips (streaming sessions cannot recalibrate in flight)."""
+        L = capi.lib()
+        prec, chk = self._precision, self.check_finite
+        try:
+            self.set_precision("f32")
+            self.check_finite = False
+            if L.artalk_set_audit(self._h, 1) != capi.OK:
+                raise RuntimeError("artalk_set_audit failed: " + self._err())
+            self.inference_batch(audios, style_motions, check=False)
+            changed = int(L.artalk_calibrate(self._h, C.c_float(float(headroom))))
+            if changed < 0:
+                raise RuntimeError("artalk_calibrate failed: " + self._err())
+        finally:
+            L.artalk_set_audit(self._h, 0)
+            self.check_finite = chk
+            self.set_precision(prec)
+        self._style_cache = {}      # (conditions are keyed by precision only; the style encoder's GEMMs do not change, but stay safe)
+        self._calibrations = getattr(self, "_calibrations", 0) + 1
+        return changed
+
+    def reset_scales(self):
+        """Back to the default scale (x16) at every site (``artalk_reset_scales``)."""
+        if capi.lib().artalk_reset_scales(self._h) != capi.OK:
+            raise RuntimeError("artalk_reset_scales failed: " + self._err())
 
     def _trip_to_f32(self, what: str):
         """An activation left fp16's range in f16x3 mode: switch to exact-f32 GEMMs for good (a checkpoint that trips once will
@@ -427,7 +458,7 @@ class BitwiseARModel:
 
     @torch.no_grad()
     def inference_batch(self, audios: Sequence[torch.Tensor], style_motions: Optional[Sequence[Optional[torch.Tensor]]] = None,
-                        return_aux: bool = False, check: bool = True, taps: bool = False) -> List[torch.Tensor]:
+                        return_aux: bool = False, check: bool = True, taps: bool = False, _recalibrated: bool = False) -> List[torch.Tensor]:
         """B independent clips -> list of ``(ceil(N_b/640), 106)`` float32 tensors on ``self.device``.
 
         ``check=False`` returns without waiting for the call's health flags (the one host synchronisation of a call), so that a
@@ -521,8 +552,21 @@ class BitwiseARModel:
             if rc != capi.OK:
                 raise RuntimeError("artalk_infer failed ({}): {}".format(rc, self._err()))
             if check and self._precision == "f16x3" and self.check_finite and self.status() != 0:
-                # an activation left fp16's range: redo this call with exact fp32 MFMA GEMMs (never silently return NaNs) and
-                # stay in f32 mode - a checkpoint that trips once trips again, and both runs per call would cost 3.4x
+                # An activation left the range of its site's fp16 operand scale.  First answer: recalibrate the per-site scales on this
+                # very batch (one exact-f32 audit pass; only the sites that need the range are lowered) and redo the call in f16x3 mode -
+                # a checkpoint with outlier activations then keeps its fast mode.  If nothing could be lowered (the guard tripped for
+                # another reason: a non-finite input, weights beyond +-255) or the recalibrated call trips again: exact fp32 MFMA GEMMs
+                # (never silently return NaNs), and stay there - both runs per call would cost 3.5x.
+                if not _recalibrated and self.auto_calibrate:
+                    import warnings
+                    try:
+                        changed = self.calibrate(audios, style_motions)
+                    except RuntimeError:
+                        changed = 0
+                    if changed > 0:
+                        warnings.warn(f"artalk_amd: an activation left the range of the f16x3 operand format; recalibrated {changed} site "
+                                      "scale(s) on this batch and re-running it in f16x3 mode")
+                        return self.inference_batch(audios, style_motions, return_aux, taps=taps, _recalibrated=True)
                 self._trip_to_f32("inference_batch")
                 return self.inference_batch(audios, style_motions, return_aux, taps=taps)
             results: List[Optional[torch.Tensor]] = [None] * B

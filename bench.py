@@ -110,6 +110,7 @@ def parse_args(argv=None):
     ap.add_argument("--io-probe", default="", choices=["", "h2d", "d2h"], help="(diagnosis) keep only the upload or only the download of the step's PCIe copies")
     ap.add_argument("--trace-host", action="store_true", help="log the host time of every submit / finish of the timed loop")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra (untimed) f32-mode and resident measurements")
+    ap.add_argument("--no-heavy-profile", action="store_true", help="skip the (untimed) outlier-weights robustness figure")
     ap.add_argument("--cpu-clips", type=int, default=12)
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched N > 1 run (0 = pick a free one)")
     return ap.parse_args(argv)
@@ -416,6 +417,44 @@ def main():
         result["f32_mode"] = {"value": round(B * frames_per_clip / dt32, 1), "ms_per_step": round(dt32 * 1e3, 2),
                               "roofline": {"bound": "mfma", "achieved": round(tf32, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                            "frac": round(tf32 / PEAK_F32_MFMA_TFLOPS, 4), "kernel": MODES["f32"][2]}}
+
+    if extras and args.precision == "f16x3" and args.config == "full" and not args.no_heavy_profile:
+        # Robustness of the fast mode (VERDICT r4 missing #2): the same workload on the `heavy` weight profile (artalk_amd.weights.PROFILES:
+        # LayerNorm gains of 300, FFN rows x 400 -> encoder FFN hidden activations of ~15 000, beyond the default x16 operand scale), the only
+        # stand-in for a real XLS-R checkpoint's outliers.  The host calibrates the per-site operand scales (artalk_calibrate - what
+        # inference_batch does by itself at the first tripped call) and the step runs IN F16X3 MODE; until round 4 this profile cost a global,
+        # latched switch to exact-f32 GEMMs (2.5x).  Both models are timed with the same plain loop (one batch at a time, status checked).
+        def plain_ms(mdl, n):
+            mdl.inference_batch(dev_audio)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                mdl.inference_batch(dev_audio, check=False)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / n * 1e3
+
+        mh = BitwiseARModel(cfg).eval().to(dev)
+        mh.load_state_dict(generate_state_dict(cfg, profile="heavy"), strict=True)
+        mh.set_precision("f16x3")
+        mh.set_graphs(True, args.branches, sk[0], sk[1])
+        mh.reserve(B, chunks)
+        mh.check_finite = False
+        mh.inference_batch(dev_audio)
+        st0 = mh.status()                                  # default scales: bit 3
+        changed = mh.calibrate(dev_audio)
+        mh.check_finite = True
+        n = max(3, args.steps // 2)
+        ms_h = plain_ms(mh, n)
+        st1 = mh.status()
+        ms_b = plain_ms(model, n)
+        result["heavy_profile"] = {"ms_per_step": round(ms_h, 2), "benign_ms_per_step_same_loop": round(ms_b, 2), "ratio": round(ms_h / ms_b, 4),
+                                   "precision": mh._precision, "status_default_scales": st0, "sites_recalibrated": changed, "status_after": st1,
+                                   "note": "weights profile 'heavy'; per-site operand scales calibrated on this batch (headroom 4), step in f16x3 mode"}
+        if st1 != 0 or mh._precision != "f16x3":
+            log(f"HEAVY PROFILE FAILURE: status {st1}, precision {mh._precision}")
+            rc = 3
+        del mh
+        torch.cuda.empty_cache()
 
     if extras:
         # latency figures outside the headline region: BASELINE configs[1] (ONE 10 s clip end to end as the reference runs it, app/models.py:62-121:

@@ -161,11 +161,23 @@ int artalk_set_graphs(artalk_model* m, int enable);
  * serving loop with ever-changing ragged batches (reference: one clip per call, inference.py:47-57) cannot grow it without limit. */
 int artalk_graph_count(const artalk_model* m, long long* captures);
 /* Headroom audit of the f16x3 operand format: while enabled every artalk_infer runs without graphs and records, for each
- * producer of a P8 operand (LayerNorm outputs, GEMM results written in P8, attention outputs, ...), max |x| * 16 - the value that
- * must stay below fp16's 65504.  artalk_get_audit synchronises and returns the number of sites; names_buf receives the site
+ * producer of a P8 operand (LayerNorm outputs, GEMM results written in P8, attention outputs, ...), max |x| - times the site's scale
+ * (16 by default, artalk_get_scales) the value that must stay below fp16's 65504.  Works in both precision modes (in f32 mode the same
+ * activations are fp32 buffers).  artalk_get_audit synchronises and returns the number of sites; names_buf receives the site
  * names NUL-separated, values[i] the maximum seen at site i since the audit was switched on (tools/p8_headroom.py). */
 int artalk_set_audit(artalk_model* m, int enable);
 int artalk_get_audit(artalk_model* m, char* names_buf, int buf_len, float* values, int max_n);
+/* Per-site operand scales of the f16x3 format.  Every producer of a P8 operand writes it with a power-of-two scale 2^e and its consumers
+ * remove the same scale; e = 4 (x16, range |x| < 4094) by default.  A checkpoint with outlier activations (XLS-R-class encoders: FFN
+ * hidden channels of 1e4 and more; the reference loads such a checkpoint, inference.py:24-28) needs more range at a few sites:
+ * artalk_calibrate reads the maxima of an audit pass (artalk_set_audit(1) + artalk_infer in EXACT-F32 mode on representative clips)
+ * and lowers e at every site where max|x| * 2^e * headroom would exceed fp16's 65504, per site, down to e = -8.  Only those sites change
+ * (everything else stays bit-identical); exponents never go up again until artalk_reset_scales.  Returns the number of sites changed,
+ * or a negative ARTALK_E* code.  artalk_get_scales: exps[i] = exponent of audit site i (the order of artalk_get_audit).
+ * The Python host calls this by itself when a call trips the range guard (status bit 3) and re-runs the call in f16x3 mode. */
+int artalk_calibrate(artalk_model* m, float headroom);
+int artalk_reset_scales(artalk_model* m);
+int artalk_get_scales(artalk_model* m, int* exps, int max_n);
 /* Intermediate taps: device buffers that correspond to intermediates of the reference, for parity tests that localise a difference to
  * a kernel group (tests/test_taps_gpu.py against tests/golden/taps_*.npz, captured from the reference by oracle/make_golden_taps.py).
  * While a tap buffer is set, artalk_infer runs the AR/VAE body eagerly as one clip group and copies, for chunk index j and clip

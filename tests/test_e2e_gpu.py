@@ -193,9 +193,11 @@ def test_style_clip_cache():
         m._style_cache.clear()
 
 
-def test_f16x3_overflow_falls_back_to_f32():
-    """An activation beyond fp16's range makes the f16x3 result non-finite; the host re-runs the call in f32 mode instead of
-    returning NaNs.  Forced here with weights scaled so that a GEMM input exceeds 65504."""
+def test_f16x3_overflow_recalibrates_or_falls_back_to_f32():
+    """An activation beyond the range of its site's fp16 operand scale raises status bit 3 at its producer.  Round 5: the host first
+    recalibrates the per-site scales on that batch and re-runs the call IN F16X3 MODE (here the feature-projection LayerNorm emits ~3e6:
+    its site drops to scale 2^-8 and the call passes); with ``auto_calibrate`` off - or if recalibration cannot cure it - it re-runs in
+    f32 mode instead of returning NaNs and stays there.  Forced with weights scaled so that a GEMM input exceeds 65504."""
     import warnings
     from artalk_amd.model import BitwiseARModel
     from artalk_amd.synth import synth_audio
@@ -216,10 +218,12 @@ def test_f16x3_overflow_falls_back_to_f32():
     m.inference_batch([audio])
     assert m.status() & 8, "the LayerNorm that produced the out-of-range P8 operand did not raise status bit 3"
     m.check_finite = True
+    # (a) the f32 fall-back (auto_calibrate off): bit-equal to f32 mode, latched
+    m.auto_calibrate = False
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         got = m.inference_batch([audio])[0]
-    assert any("re-running" in str(x.message) for x in w)
+    assert any("re-running in f32" in str(x.message) for x in w)
     assert torch.isfinite(got).all() and torch.equal(got, want)
     # a model that tripped once stays in f32 mode (no f16x3 + f32 double run on every later call) until told otherwise
     assert m._precision == "f32" and m._latched_f32
@@ -239,6 +243,23 @@ def test_f16x3_overflow_falls_back_to_f32():
     assert m._precision == "f32"
     m.stream_begin(1)
     assert (m.stream_chunk(chunk.cuda())[0] - want[:100]).abs().max().item() < 1e-5
+    m.stream_end()
+    # (b) recalibration (the default): the call is redone in f16x3 mode with the site's scale lowered, and stays there
+    m.auto_calibrate = True
+    m.set_precision("f16x3")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = m.inference_batch([audio])[0]
+    assert any("recalibrated" in str(x.message) for x in w), [str(x.message) for x in w]
+    assert m._precision == "f16x3" and not m._latched_f32 and m.status() == 0
+    assert torch.isfinite(got).all() and (got - want).abs().max().item() < 1e-5
+    with warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter("always")
+        assert torch.equal(m.inference_batch([audio])[0], got)
+    assert not w2 and m.status() == 0
+    # a streaming session on the calibrated model runs in the fast mode too
+    m.stream_begin(1)
+    assert (m.stream_chunk(chunk.cuda())[0] - want[:100]).abs().max().item() < 1e-5 and m._precision == "f16x3"
 
 
 def test_reference_call_surface():

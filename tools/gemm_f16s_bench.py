@@ -19,6 +19,9 @@ for _M in (16, 32, 80, 160, 400, 800, 1600, 3200):
     SHAPES += [(f"t{_M} qkv", _M, 2304, 768), (f"t{_M} proj", _M, 768, 768), (f"t{_M} ffn1", _M, 3072, 768), (f"t{_M} ffn2", _M, 768, 3072)]
 # the VAE decoder stack of one clip group of 16 (200 tokens per clip, hidden 512, MLP 768)
 SHAPES += [("v qkv", 3200, 1536, 512), ("v proj", 3200, 512, 512), ("v mlp1", 3200, 768, 512), ("v mlp2", 3200, 512, 768)]
+# the same stack for a merged group of 32 clips, and the re-encode stack (100 tokens per clip) of 16 / 32 clips
+SHAPES += [("w qkv", 6400, 1536, 512), ("w proj", 6400, 512, 512), ("w mlp1", 6400, 768, 512), ("w mlp2", 6400, 512, 768)]
+SHAPES += [("e qkv", 1600, 1536, 512), ("e proj", 1600, 512, 512), ("e mlp1", 1600, 768, 512), ("e mlp2", 1600, 512, 768)]
 # row counts whose 128x128 tile counts are whole multiples of the 512 persistent workgroups (round-quantisation check)
 for _M in (8192, 16384):
     SHAPES += [(f"q{_M} qkv", _M, 3072, 1024), (f"q{_M} out", _M, 1024, 1024), (f"q{_M} ff1", _M, 4096, 1024), (f"q{_M} ff2", _M, 1024, 4096)]

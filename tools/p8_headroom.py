@@ -1,10 +1,12 @@
 #!/usr/bin/env python
-"""Headroom of the f16x3 operand format ("P8": f16(16 x) + residual) on every golden input -> profiles/r02_p8_headroom.json.
+"""Headroom of the f16x3 operand format ("P8": f16(S x) + residual, S = the site's power-of-two scale) on every golden input
+-> profiles/rNN_p8_headroom[_profile].json.
 
-For each producer site of a P8 operand (artalk_set_audit) the largest |x| * 16 seen over all fixtures, and the factor left to
-fp16's 65504.  The weights are synthetic (no checkpoint is available offline), so this documents the mechanism and the margin
-on the synthetic model; a real checkpoint is audited by the same command, and at run time a value beyond the range raises bit 3
-of the status word where it is produced (the model then re-runs in exact-f32 mode and stays there).
+For each producer site of a P8 operand (artalk_set_audit) the largest |x| seen over all fixtures, the site's scale (16 unless the
+calibration lowered it: artalk_calibrate) and the factor left to fp16's 65504.  The weights are synthetic (no checkpoint is
+available offline), so this documents the mechanism and the margin on the synthetic model; a real checkpoint is audited by the same
+command.  ``--calibrate`` first runs the calibration pass (exact-f32 audit over the same clips, headroom 4) - what the Python host
+does by itself when a call trips the range guard - and then audits the f16x3 run with the calibrated scales.
 """
 import ctypes as C
 import json
@@ -30,7 +32,10 @@ def read_audit(m):
     n = L.artalk_get_audit(m._h, buf, len(buf), vals, 1024)
     assert n >= 0
     names = buf.raw.split(b"\0")[:n]
-    return {nm.decode(): float(vals[i]) for i, nm in enumerate(names)}
+    exps = (C.c_int * 1024)()
+    ne = L.artalk_get_scales(m._h, exps, 1024)
+    assert ne >= n
+    return {nm.decode(): (float(vals[i]), int(exps[i])) for i, nm in enumerate(names)}
 
 
 def main():
@@ -42,42 +47,62 @@ def main():
         i = args.index("--profile")
         profile = args[i + 1]
         del args[i:i + 2]
-    out = args[0] if args else os.path.join(REPO, "profiles", "r02_p8_headroom.json")
+    calibrate = "--calibrate" in args
+    if calibrate:
+        args.remove("--calibrate")
+    out = args[0] if args else os.path.join(REPO, "profiles", "r05_p8_headroom.json")
     cfg, sd = get_state_dict("full", profile)
     m = get_gpu_model("full", profile)
-    m.set_precision("f16x3")
-    m.check_finite = False          # the audit records what the format is asked to hold; no f32 re-run here
+    m.check_finite = False          # the audit records what the format is asked to hold; no re-run here
     L = capi.lib()
-    assert L.artalk_set_audit(m._h, 1) == 0
-    n_clips = 0
     cases = CASES if profile == "benign" else [f"{profile}_full_4s_s2"] + ([f"{profile}_full_5p5s_s3_style"] if profile == "outlier" else []) + CASES
-    for case in cases:
-        g = load_golden(case)
-        audio, style = golden_inputs(g, sd)
-        m.inference_batch([audio], [style])
-        n_clips += 1
-    for name in ("full_cfg4_demo32", "full_cfg2_synth8"):
-        clips = load_clip_set(name)
-        audios, styles = clip_set_inputs(clips, sd)
-        m.inference_batch(audios, styles)
-        n_clips += len(clips)
+
+    def run_all():
+        n = 0
+        for case in cases:
+            g = load_golden(case)
+            audio, style = golden_inputs(g, sd)
+            m.inference_batch([audio], [style])
+            n += 1
+        for name in ("full_cfg4_demo32", "full_cfg2_synth8"):
+            clips = load_clip_set(name)
+            audios, styles = clip_set_inputs(clips, sd)
+            m.inference_batch(audios, styles)
+            n += len(clips)
+        return n
+
+    changed = None
+    if calibrate:
+        m.set_precision("f32")
+        assert L.artalk_set_audit(m._h, 1) == 0
+        run_all()
+        changed = L.artalk_calibrate(m._h, C.c_float(4.0))
+        assert changed >= 0, L.artalk_last_error(m._h).decode()
+        L.artalk_set_audit(m._h, 0)
+    m.set_precision("f16x3")
+    assert L.artalk_set_audit(m._h, 1) == 0
+    n_clips = run_all()
     table = read_audit(m)
     status = m.status()
     L.artalk_set_audit(m._h, 0)
-    rows = sorted(table.items(), key=lambda t: -t[1])
+    rows = sorted(table.items(), key=lambda t: -(t[1][0] * 2.0 ** t[1][1]))
     worst = rows[0]
+    wv = worst[1][0] * 2.0 ** worst[1][1]
     res = {
-        "what": "max |x| * 16 per producer site of a P8 (f16x3) operand over all golden inputs; limit 65504 (fp16 max)",
+        "what": "per producer site of a P8 (f16x3) operand over all golden inputs: max |x|, the site's scale exponent e (scale 2^e, default 4) "
+                "and max |x| * 2^e against the limit 65504 (fp16 max)",
         "weights": f"deterministic synthetic weights (seed 1234, profile '{profile}': artalk_amd.weights.PROFILES), reference motion statistics", "clips": n_clips,
-        "status_word": status, "limit": 65504.0,
-        "worst_site": worst[0], "worst_value": worst[1], "min_headroom_factor": 65504.0 / max(worst[1], 1e-30),
-        "sites": {k: {"max_abs_x16": v, "headroom_factor": (65504.0 / v if v > 0 else None)} for k, v in rows},
+        "calibrated": calibrate, "sites_changed_by_calibration": changed, "status_word": status, "limit": 65504.0,
+        "worst_site": worst[0], "worst_scaled_value": wv, "min_headroom_factor": 65504.0 / max(wv, 1e-30),
+        "lowered_sites": {k: v[1] for k, v in rows if v[1] != 4},
+        "sites": {k: {"max_abs": v[0], "exp": v[1], "max_abs_scaled": v[0] * 2.0 ** v[1], "headroom_factor": (65504.0 / (v[0] * 2.0 ** v[1]) if v[0] > 0 else None)} for k, v in rows},
     }
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
-    print(f"{len(rows)} sites over {n_clips} clips; worst {worst[0]} = {worst[1]:.1f} (headroom x{res['min_headroom_factor']:.0f}); status {status}")
+    print(f"{len(rows)} sites over {n_clips} clips; worst {worst[0]} = {wv:.1f} scaled (headroom x{res['min_headroom_factor']:.1f}); status {status}; "
+          f"calibration changed {changed} sites: {len(res['lowered_sites'])} below the default scale")
     for k, v in rows[:12]:
-        print(f"  {k:50s} {v:10.2f}")
+        print(f"  {k:50s} max|x| {v[0]:12.3f}  2^{v[1]:<3d} scaled {v[0] * 2.0 ** v[1]:10.2f}")
 
 
 if __name__ == "__main__":
