@@ -495,17 +495,19 @@ bool gemm(artalk_model* m, const GemmArgs& g0, hipStream_t s, const LnArgs* fuse
             // ~150 tiles the 64x64 kernel wins: projection at M = 1600 14.0 vs 19.0).  It has no second P8 copy of the result (c2).
             if (S == 1 && g.force_cfg < 0 && !g.c2) {
                 const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128);
-                // (experiment, ARTALK_PP: bit 0 = the ping-pong 256 x 128 kernel (cfg 31) for unsplit launches with >= ARTALK_PP_MIN of its
-                // tiles; bit 1 = its 128 x 128 form (cfg 33) in place of the mid-grid kernel)
-                static const int pp_mode = getenv("ARTALK_PP") ? atoi(getenv("ARTALK_PP")) : 0;
+                // Ping-pong kernel (gemm_p8_pp_kernel, cfg 31: 256 x 128 tiles, the two waves of a SIMD one phase apart) where its grid is
+                // 120 .. 256 tiles: q|k|v and FFN-in of the 100-token step, q|k|v of the VAE decoder stack.  Measured (round 5,
+                // profiles/r05_pp_gemm_sweep.log, r05_pp_model_ab.log): FFN-in at M = 1600 39.0 -> 32.6 us (168 tiles in ONE round instead
+                // of 312 in two), VAE q|k|v at M = 3200 27.1 -> 24.2, q|k|v at M = 1600 slower alone (24.3 -> 30.8: half the chip) but not
+                // beside the other clip group's launches; body 31.75 / 31.92 -> 31.58 / 31.79 ms per step in same-box pairs.  The
+                // 128 x 128 form (cfg 33) equals the mid-grid kernel on every shape.  ARTALK_PP=0 switches it off (A/B), 2 / 3 add cfg 33.
+                static const int pp_mode = getenv("ARTALK_PP") ? atoi(getenv("ARTALK_PP")) : 1;
                 static const int pp_min = getenv("ARTALK_PP_MIN") ? atoi(getenv("ARTALK_PP_MIN")) : 120;
                 const int t256 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
-                if ((pp_mode & 1) && t256 >= pp_min && t256 <= 256) cfg = 31;
-                else if (t128 >= 150) cfg = (pp_mode & 2) ? 33 : 28;
+                if ((pp_mode & 1) && t256 >= pp_min && t256 <= 256 && gemm_p8_pp_ok(g)) cfg = 31;
+                else if (t128 >= 150) cfg = ((pp_mode & 2) && gemm_p8_pp_ok(g)) ? 33 : 28;
                 if (cfg == 31 || cfg == 33) g.force_cfg = cfg;
-                else
-                if (t128 >= 150) cfg = 28;
-                else if (g.K >= 2048 && 3 * t128 >= 150 && (int64_t)3 * g.M * g.N <= cw.splitk_floats) { S = 3; cfg = 28; }
+                else if (t128 < 150 && g.K >= 2048 && 3 * t128 >= 150 && (int64_t)3 * g.M * g.N <= cw.splitk_floats) { S = 3; cfg = 28; }
                 if (cfg == 28 && S == 1) g.force_cfg = 28;
             }
             if (S > 1) { g.splitk = S; g.partial = cw.splitk; if (g.force_cfg < 0) g.force_cfg = cfg; }

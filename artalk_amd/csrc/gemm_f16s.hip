@@ -1917,15 +1917,13 @@ bool gemm_p8_pp_ok(const GemmArgs& g) {
 void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return;
     int cfg = g.force_cfg;
-    if (cfg >= 30 && cfg <= 35 && !gemm_p8_pp_ok(g)) cfg = 28;
+    if (cfg >= 30 && cfg <= 33 && !gemm_p8_pp_ok(g)) cfg = 28;
     switch (cfg) {
-        // ping-pong kernel (round 5): 30 / 31 = 256 x 128 tile, 3 stages, one / two barriers per K step; 32 / 33 = 128 x 128, 4 stages; 34 / 35 = 128 x 256, 3 stages
+        // ping-pong kernel (round 5): 30 / 31 = 256 x 128 tile, 3 stages, one / two barriers per K step; 33 = 128 x 128, 4 stages, two barriers
+        // (one barrier per step and the 128 x 256 tile measured no better: profiles/r05_pp_gemm_sweep.log)
         case 30: launch_p8_pp<256, 128, 4, 2, 3, 0>(g, s); break;
         case 31: launch_p8_pp<256, 128, 4, 2, 3, 1>(g, s); break;
-        case 32: launch_p8_pp<128, 128, 2, 4, 4, 0>(g, s); break;
         case 33: launch_p8_pp<128, 128, 2, 4, 4, 1>(g, s); break;
-        case 34: launch_p8_pp<128, 256, 2, 4, 3, 0>(g, s); break;
-        case 35: launch_p8_pp<128, 256, 2, 4, 3, 1>(g, s); break;
         case 28: launch_p8_mid<4>(g, s); break;
         case 29: launch_p8_mid<5>(g, s); break;      // (experiment: the whole 160 KiB of LDS as a ring of 5 stages, four K tiles in flight)
         case 23: launch_p8_sm_cfg<64, 64, 8>(g, s); break;
@@ -1962,12 +1960,9 @@ void gemm_p8_prepare() {      // more than the default 64 KB of dynamic LDS (out
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_mid_kernel<5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128);
     {
         const void* pp[] = {reinterpret_cast<const void*>(&gemm_p8_pp_kernel<256, 128, 4, 2, 3, 0, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<256, 128, 4, 2, 3, 0, 1>),
-                            reinterpret_cast<const void*>(&gemm_p8_pp_kernel<256, 128, 4, 2, 3, 1, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<256, 128, 4, 2, 3, 1, 1>),
-                            reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 256, 2, 4, 3, 0, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 256, 2, 4, 3, 0, 1>),
-                            reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 256, 2, 4, 3, 1, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 256, 2, 4, 3, 1, 1>)};
+                            reinterpret_cast<const void*>(&gemm_p8_pp_kernel<256, 128, 4, 2, 3, 1, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<256, 128, 4, 2, 3, 1, 1>)};
         for (const void* f : pp) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 384 * 128);
-        const void* pq[] = {reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 128, 2, 4, 4, 0, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 128, 2, 4, 4, 0, 1>),
-                            reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 128, 2, 4, 4, 1, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 128, 2, 4, 4, 1, 1>)};
+        const void* pq[] = {reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 128, 2, 4, 4, 1, 0>), reinterpret_cast<const void*>(&gemm_p8_pp_kernel<128, 128, 2, 4, 4, 1, 1>)};
         for (const void* f : pq) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128);
     }
     done[dev] = true;

@@ -79,6 +79,7 @@ void gemm_p8_prepare();      // one-time kernel attributes (call once per proces
 int gemm_p8_variant(const GemmArgs& g);       // 0: gemm_p8_2wgp_kernel (persistent 128x128, two workgroups per CU), 1: gemm_p8_256_kernel
 bool gemm_p8_sm_eligible(const GemmArgs& g);   // both operands in P8, any grid (split-K capable): small-tile LDS-DMA kernel
 void launch_gemm_p8_sm(const GemmArgs& g, hipStream_t s);
+bool gemm_p8_pp_ok(const GemmArgs& g);      // operands within the 32-bit DMA offsets of the ping-pong kernel (launch_gemm_p8_sm cfg 30 / 31 / 33)
 // wav2vec2 positional convolution (16 groups of 64 channels, 128 taps) with the chunk's input window resident in LDS (gemm_f16s.hip)
 void launch_posconv_p8(const GemmArgs& g, int n_chunks, int T, int Ts, hipStream_t s);
 int gemm_config(const GemmArgs& g);   // 4: 128x128 BK16 (dominant kernel), 2: 64x64, 1: 128x64, 3: 32x128; 0,5,6,7 tuning variants

@@ -116,7 +116,7 @@ def test_gemm_p8_dma_pipeline_and_producers():
     # 256x256 kernel, 8 = persistent two-workgroup 128x128 (deferred epilogue), 99 = launch_gemm_p8's own choice; register-staged
     # 128x128 and 64x64 (0, 1); the small-grid LDS-DMA kernel (20) and its deep-ring split-K configurations (23, 24; cfg | S << 8 =
     # split-K S), all fed with the P8 activation
-    for cfg in (7, 12, 13, 8, 99, 0, 1, 20, 20 | (3 << 8), 23 | (4 << 8), 24 | (6 << 8), 28, 28 | (3 << 8)):      # 28: the mid-grid 128x128 kernel
+    for cfg in (7, 12, 13, 8, 99, 0, 1, 20, 20 | (3 << 8), 23 | (4 << 8), 24 | (6 << 8), 28, 28 | (3 << 8), 30, 31, 33, 31 | (3 << 8), 33 | (2 << 8)):      # 28: the mid-grid 128x128 kernel; 30 / 31 / 33: the ping-pong kernel (256x128 with one / two barriers per K step, 128x128)
         out.fill_(float("nan"))
         assert L.artalk_op_gemm_f16s_packed(_p(Ap), 1, K, _p(Wp), _p(db), _p(out), M, N, K, 0, cfg, None) == 0
         torch.cuda.synchronize()
@@ -124,7 +124,7 @@ def test_gemm_p8_dma_pipeline_and_producers():
         assert err < 2e-6, (cfg, err)
     # small ragged shapes of the AR scale steps through the small-grid kernel (M = 80 / 400 rows, K = 1024 here)
     for Ms in (80, 400):
-        for cfg in (20, 20 | (4 << 8), 23 | (8 << 8), 24 | (2 << 8), 8, 28, 28 | (2 << 8)):     # 8: the large-grid kernel on a grid smaller than the chip (one tile per workgroup)
+        for cfg in (20, 20 | (4 << 8), 23 | (8 << 8), 24 | (2 << 8), 8, 28, 28 | (2 << 8), 31, 33, 31 | (4 << 8)):     # 8: the large-grid kernel on a grid smaller than the chip (one tile per workgroup)
             o2 = torch.full((Ms, N), float("nan"), device="cuda")
             assert L.artalk_op_gemm_f16s_packed(_p(Ap), 1, K, _p(Wp), _p(db), _p(o2), Ms, N, K, 0, cfg, None) == 0
             torch.cuda.synchronize()
