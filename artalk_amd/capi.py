@@ -20,7 +20,7 @@ DTYPE_F32, DTYPE_I64 = 0, 1
 SYMBOLS = [
     "artalk_create", "artalk_destroy", "artalk_last_error", "artalk_set_tensor", "artalk_finalize_weights",
     "artalk_reserve", "artalk_workspace_bytes", "artalk_weight_bytes", "artalk_infer", "artalk_get_status", "artalk_poll_status", "artalk_last_ticket", "artalk_get_status_of", "artalk_style_encode", "artalk_stream_begin", "artalk_stream_chunk", "artalk_stream_end", "artalk_savgol", "artalk_flame_create", "artalk_flame_verts", "artalk_flame_destroy", "artalk_flame_last_error",
-    "artalk_set_profiling", "artalk_get_profile", "artalk_set_graphs", "artalk_graph_count", "artalk_set_cu_mask", "artalk_set_audit", "artalk_get_audit", "artalk_calibrate", "artalk_reset_scales", "artalk_get_scales", "artalk_set_tap", "artalk_tap_layout", "artalk_set_precision",
+    "artalk_set_profiling", "artalk_get_profile", "artalk_get_kernel_sums", "artalk_set_graphs", "artalk_graph_count", "artalk_set_cu_mask", "artalk_set_audit", "artalk_get_audit", "artalk_calibrate", "artalk_reset_scales", "artalk_get_scales", "artalk_set_tap", "artalk_tap_layout", "artalk_set_precision",
     "artalk_op_gemm", "artalk_op_gemm_ex", "artalk_op_gemm_f16s", "artalk_op_pack_split", "artalk_op_gemm_f16s_packed", "artalk_op_release_scratch", "artalk_op_gemm_p8_plan", "artalk_op_create_masked_stream", "artalk_op_destroy_stream", "artalk_op_mfma_f32_peak", "artalk_op_layernorm", "artalk_op_attention", "artalk_op_w2v_front", "artalk_op_resample_mean", "artalk_op_pool_silu",
     "artalk_op_bsq_history",
 ]
@@ -130,6 +130,9 @@ def lib() -> C.CDLL:
     L.artalk_set_profiling.restype = i32
     L.artalk_get_profile.argtypes = [vp, C.POINTER(C.c_double), i32]
     L.artalk_get_profile.restype = i32
+    if hasattr(L, "artalk_get_kernel_sums"):      # (round 5)
+        L.artalk_get_kernel_sums.argtypes = [vp, C.POINTER(C.c_double), i32]
+        L.artalk_get_kernel_sums.restype = i32
     L.artalk_set_graphs.argtypes = [vp, i32]
     L.artalk_set_graphs.restype = i32
     if hasattr(L, "artalk_graph_count"):      # (round 5; an older build loaded through ARTALK_LIB lacks it)

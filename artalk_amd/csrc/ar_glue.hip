@@ -110,7 +110,7 @@ void launch_absmax(const float* buf, int rows, int cols, long ld, int is_p8, uns
     if (rows <= 0 || cols < 8) return;
     const long groups = (long)rows * (cols / 8);
     const long blocks = (groups + 255) / 256;
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, buf, rows, cols, ld, is_p8, slot, junk_period,
+    ARTALK_LAUNCH(absmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, buf, rows, cols, ld, is_p8, slot, junk_period,
                        junk_from, p8_scale_of(-p8_exp));
 }
 
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void ar_begin_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < T100 * CD; i += 256) fhat[(long)b * T100 * CD + i] = 0.f;
 }
 void launch_ar_begin(const float* style_cond, const float* lvlpos, float* x0, float* fhat, int B, hipStream_t s) {
-    hipLaunchKernelGGL(ar_begin_kernel, dim3(B), dim3(256), 0, s, style_cond, lvlpos, x0, fhat, 768);
+    ARTALK_LAUNCH(ar_begin_kernel, dim3(B), dim3(256), 0, s, style_cond, lvlpos, x0, fhat, 768);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(BITS_NT) void ar_bits_kernel(const float* __restric
         nextfeat[(long)b * pn2 * CD + idx] = area_pool(fs, pn2, idx / CD, idx % CD);
 }
 void launch_ar_bits_next(const float* logits, uint8_t* bits, float* fhat, float* nextfeat, int B, int level, hipStream_t s, int* status) {
-    hipLaunchKernelGGL(ar_bits_kernel, dim3(B), dim3(BITS_NT), 0, s, logits, bits, fhat, nextfeat, level, status);
+    ARTALK_LAUNCH(ar_bits_kernel, dim3(B), dim3(BITS_NT), 0, s, logits, bits, fhat, nextfeat, level, status);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void vq_embed_kernel(const float* __restrict__
 }
 void launch_vq_embed(const float* feat, int n, const float* We, const float* be, const float* pos, float* X, int xrows,
                      int xoff, const float* style_cond, const float* pos0, int B, hipStream_t s) {
-    hipLaunchKernelGGL(vq_embed_kernel, dim3((n + VQ_TOK - 1) / VQ_TOK, B), dim3(256), 0, s, feat, n, We, be, pos, X, xrows, xoff,
+    ARTALK_LAUNCH(vq_embed_kernel, dim3((n + VQ_TOK - 1) / VQ_TOK, B), dim3(256), 0, s, feat, n, We, be, pos, X, xrows, xoff,
                        style_cond, pos0, 768);
 }
 
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void dec_input_kernel(const float* __restrict_
 }
 void launch_dec_input(const float* prev_fdec, const float* fhat, const uint8_t* bits, const float* dpos, float* X, int B,
                       hipStream_t s) {
-    hipLaunchKernelGGL(dec_input_kernel, dim3(B, 8), dim3(256), 0, s, prev_fdec, fhat, bits, dpos, X);
+    ARTALK_LAUNCH(dec_input_kernel, dim3(B, 8), dim3(256), 0, s, prev_fdec, fhat, bits, dpos, X);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void dec_finish_kernel(const float* __restrict
 }
 void launch_dec_finish(const float* dec, const float* mean, const float* stdv, const float* epos, float* out,
                        long out_bstride, int chunk, float* E, int B, hipStream_t s, int* status) {
-    hipLaunchKernelGGL(dec_finish_kernel, dim3(B, 10), dim3(256), 0, s, dec, mean, stdv, epos, out, out_bstride, chunk, E, 106, 128, status);
+    ARTALK_LAUNCH(dec_finish_kernel, dim3(B, 10), dim3(256), 0, s, dec, mean, stdv, epos, out, out_bstride, chunk, E, 106, 128, status);
 }
 
 __global__ __launch_bounds__(256) void enc_input_zero_kernel(const float* __restrict__ mean, const float* __restrict__ stdv,
@@ -285,12 +285,12 @@ __global__ __launch_bounds__(256) void broadcast16_kernel(const uint4* __restric
 void launch_broadcast16(const void* src, void* dst, long bytes, int B, hipStream_t s) {
     if (B <= 0 || bytes <= 0) return;
     const int n16 = (int)(bytes / 16);
-    hipLaunchKernelGGL(broadcast16_kernel, dim3((n16 + 255) / 256 < 8 ? (n16 + 255) / 256 : 8, B), dim3(256), 0, s,
+    ARTALK_LAUNCH(broadcast16_kernel, dim3((n16 + 255) / 256 < 8 ? (n16 + 255) / 256 : 8, B), dim3(256), 0, s,
                        reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16);
 }
 
 void launch_enc_input_zero(const float* mean, const float* stdv, const float* epos, float* E, int B, hipStream_t s) {
-    hipLaunchKernelGGL(enc_input_zero_kernel, dim3(B), dim3(256), 0, s, mean, stdv, epos, E, 106, 128);
+    ARTALK_LAUNCH(enc_input_zero_kernel, dim3(B), dim3(256), 0, s, mean, stdv, epos, E, 106, 128);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(BSQ_NT) void bsq_history_kernel(const float* __rest
     }
 }
 void launch_bsq_history(const float* enc_out, uint8_t* hist_bits, float* prev_fdec, float* msfeat, int B, hipStream_t s, int* status) {
-    hipLaunchKernelGGL(bsq_history_kernel, dim3(B), dim3(BSQ_NT), 0, s, enc_out, hist_bits, prev_fdec, msfeat, status);
+    ARTALK_LAUNCH(bsq_history_kernel, dim3(B), dim3(BSQ_NT), 0, s, enc_out, hist_bits, prev_fdec, msfeat, status);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void style_input_kernel(const float* __restric
 }
 void launch_style_input(const float* motion, const float* mean, const float* stdv, float* X, int B, hipStream_t s) {
     const int rows = B * 50;
-    hipLaunchKernelGGL(style_input_kernel, dim3((rows * 128 + 255) / 256), dim3(256), 0, s, motion, mean, stdv, X, rows, 106, 128);
+    ARTALK_LAUNCH(style_input_kernel, dim3((rows * 128 + 255) / 256), dim3(256), 0, s, motion, mean, stdv, X, rows, 106, 128);
 }
 
 __global__ __launch_bounds__(256) void add_row_kernel(float* __restrict__ X, const float* __restrict__ v, long n, int D) {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void add_row_kernel(float* __restrict__ X, con
 }
 void launch_add_row(float* X, const float* v, int M, int D, hipStream_t s) {
     const long n = (long)M * D;
-    hipLaunchKernelGGL(add_row_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, v, n, D);
+    ARTALK_LAUNCH(add_row_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, v, n, D);
 }
 
 __global__ __launch_bounds__(256) void style_finish_kernel(const float* __restrict__ feat, const float* __restrict__ Ws,
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void style_finish_kernel(const float* __restri
 }
 void launch_style_finish(const float* feat, const float* Ws, const float* bs, const float* null_cond,
                          const uint8_t* has_style, float* style_cond, int B, hipStream_t s, const float* cached, long cached_stride) {
-    hipLaunchKernelGGL(style_finish_kernel, dim3(B), dim3(256), 0, s, feat, Ws, bs, null_cond, has_style, style_cond, 50, 128, 768,
+    ARTALK_LAUNCH(style_finish_kernel, dim3(B), dim3(256), 0, s, feat, Ws, bs, null_cond, has_style, style_cond, 50, 128, 768,
                        cached, cached_stride);
 }
 
@@ -476,7 +476,7 @@ void launch_savgol(const float* in, float* out, int T, int D, hipStream_t s) {
         polyfit_edge(9, 3, 4, &k.edge9[0][0], k.fir9);
     });
     if (T < 9) abort();   // the Python host raises ValueError first (scipy does the same for mode='interp')
-    hipLaunchKernelGGL(savgol_kernel, dim3(T), dim3(128), 0, s, in, out, T, D, k);
+    ARTALK_LAUNCH(savgol_kernel, dim3(T), dim3(128), 0, s, in, out, T, D, k);
 }
 
 }  // namespace artalk

@@ -1375,9 +1375,9 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.Lq <= 0) return;
     if (a.HD == 64 && a.split_q == 0 && a.Lq <= 64 && a.Lk >= 64 && !a.qkv_p8) {      // AR scale steps 0-3: key-split kernel
         const dim3 grid(((a.H * a.B + 7) / 8) * 8 * ((a.Lq + 15) / 16));
-        if (a.slabs && a.Lq <= 16) hipLaunchKernelGGL((attention_short_kernel<64, true>), grid, dim3(256), 0, s, a);
+        if (a.slabs && a.Lq <= 16) ARTALK_LAUNCH((attention_short_kernel<64, true>), grid, dim3(256), 0, s, a);
         else if (a.slabs) abort();      // (slabs are only handed over for one query tile per head: engine.hip run_chunk_body)
-        else hipLaunchKernelGGL((attention_short_kernel<64, false>), grid, dim3(256), 0, s, a);
+        else ARTALK_LAUNCH((attention_short_kernel<64, false>), grid, dim3(256), 0, s, a);
         return;
     }
     dim3 grid((a.Lq + 63) / 64, a.H, a.B), block(256);
@@ -1398,22 +1398,22 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         if (!n_cu && (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)) n_cu = 256;
         const int cus = a.cus > 0 ? (a.cus < n_cu ? a.cus : n_cu) : n_cu;
         if (pp && wide != 2 && a.split_q <= 0 && a.Lk > kPPRowsA && a.Lk <= kPPRowsA + kPPRowsB && (long)a.B * a.H >= 2L * cus) {
-            hipLaunchKernelGGL((attention_f16_pp_kernel<1>), dim3(cus), dim3(kPPWaves * 64), (size_t)4 * (kPPRowsA + kPPRowsB) * 160, s, a);
+            ARTALK_LAUNCH((attention_f16_pp_kernel<1>), dim3(cus), dim3(kPPWaves * 64), (size_t)4 * (kPPRowsA + kPPRowsB) * 160, s, a);
             return;
         }
-        if (wide == 2 || (long)a.B * a.H < 256) hipLaunchKernelGGL((attention_f16_wide_ar_kernel<1, 1, 7, 128>), dim3((a.Lq + 111) / 112, a.H, a.B), dim3(7 * 64), (size_t)4 * 128 * 160, s, a);
-        else hipLaunchKernelGGL((attention_f16_wide_kernel<1>), dim3(1, a.H, a.B), dim3(kWideMaxWaves * 64), lds, s, a);
+        if (wide == 2 || (long)a.B * a.H < 256) ARTALK_LAUNCH((attention_f16_wide_ar_kernel<1, 1, 7, 128>), dim3((a.Lq + 111) / 112, a.H, a.B), dim3(7 * 64), (size_t)4 * 128 * 160, s, a);
+        else ARTALK_LAUNCH((attention_f16_wide_kernel<1>), dim3(1, a.H, a.B), dim3(kWideMaxWaves * 64), lds, s, a);
     } else if (a.HD == 64 && a.split16 && a.qkv_p8 && !a.l2norm)
-        hipLaunchKernelGGL((attention_f16_kernel<1, 1>), grid, block, 0, s, a);
+        ARTALK_LAUNCH((attention_f16_kernel<1, 1>), grid, block, 0, s, a);
     else if (a.HD == 64 && a.split16 && wide && !a.qkv_p8 && a.split_q == 0 && a.Lq > 32 && a.Lq <= kWideArWaves * 16 && a.Lk > 64) {
         attention_prepare();      // the 100-query scale step of the AR decoder: one workgroup per (clip, head), 192 keys per staging phase
-        hipLaunchKernelGGL((attention_f16_wide_ar_kernel<1>), dim3(1, a.H, a.B), dim3(kWideArWaves * 64), (size_t)4 * kWideArKeys * 160, s, a);
+        ARTALK_LAUNCH((attention_f16_wide_ar_kernel<1>), dim3(1, a.H, a.B), dim3(kWideArWaves * 64), (size_t)4 * kWideArKeys * 160, s, a);
     } else if (a.HD == 64 && a.split16)
-        hipLaunchKernelGGL(attention_f16_kernel<1>, grid, block, 0, s, a);
+        ARTALK_LAUNCH(attention_f16_kernel<1>, grid, block, 0, s, a);
     else if (a.HD == 64)
-        hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, a);
+        ARTALK_LAUNCH(attention_kernel<64>, grid, block, 0, s, a);
     else if (a.HD == 32)
-        hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, s, a);
+        ARTALK_LAUNCH(attention_kernel<32>, grid, block, 0, s, a);
     else
         abort();
 }

@@ -27,7 +27,26 @@
 
 using namespace artalk;
 
+namespace artalk {
+thread_local KernelTimer* g_ktimer = nullptr;
+bool ktimer_events(hipEvent_t* e0, hipEvent_t* e1) {
+    KernelTimer* t = g_ktimer;
+    if (!t) return false;
+    while (t->pool.size() < t->used + 2) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return false;
+        t->pool.push_back(e);
+    }
+    *e0 = t->pool[t->used]; *e1 = t->pool[t->used + 1];
+    t->recs.emplace_back(t->bucket, t->used);
+    t->used += 2;
+    return true;
+}
+}  // namespace artalk
+
 namespace {
+// buckets of the kernel timer (artalk_get_kernel_sums): stages of the path, the scale steps of the body
+enum { KB_STYLE = 0, KB_CONV = 1, KB_ENC = 2, KB_ADA = 3, KB_AR_MISC = 4, KB_LEVEL0 = 5, KB_VAE_DEC = 10, KB_REENC = 11, KB_OTHER = 12, KB_N = 13 };
 
 thread_local std::string g_create_error;
 
@@ -160,7 +179,8 @@ struct artalk_model {
     std::vector<StyleLayer> style;
     Workspace ws;
     // profiling
-    int profiling = 0;        // 0 off, 1 light (graphs stay on; events around eager launches only), 2 full (graphs off)
+    int profiling = 0;        // 0 off, 1 light (graphs stay on; events around eager launches only), 2 full (graphs off), 3 kernel timer (graphs off, one clip group, every launch timed)
+    KernelTimer ktimer;       // level 3: per-kernel durations by bucket (artalk_get_kernel_sums)
     bool use_graphs = true;
     bool in_graph_body = false;   // capturing: no events
     bool in_body = false;         // inside run_chunk_body (captured or eager)
@@ -419,6 +439,7 @@ hipEvent_t next_event(artalk_model* m, hipStream_t s, size_t* idx) {
 }
 // profile buckets (artalk_get_profile): the interval that ENDS at a mark is charged to the mark's bucket
 enum { PB_STYLE = 0, PB_CONV = 1, PB_ENC = 2, PB_ADA = 3, PB_AR = 4, PB_VAE = 5, PB_OTHER = 6 };
+void kbucket(artalk_model* m, int b) { m->ktimer.bucket = b; }
 void stage_mark(artalk_model* m, hipStream_t s, int bucket) {
     if (!m->profiling || m->in_graph_body) return;
     size_t i;
@@ -596,6 +617,7 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     const int AP = p8 ? LF_A_P8 : 0;
     Range r_w2v("artalk.wav2vec2");
     roctxRangePushA("artalk.wav2vec2.conv_stack");      // K1-K3: normalise, conv0+LN+GELU, conv1-6 as GEMMs + LN + GELU
+    kbucket(m, KB_CONV);
     launch_audio_normalize(audio, w.src_off + c0, w.xnorm, n, kSamplesPerChunk, s);
     SiteExps& ex = m->ex;
     launch_conv0(w.xnorm, kSamplesPerChunk, m->conv0_w, m->conv_b[0], m->conv_lnw[0], m->conv_lnb[0], w.convA, n, m->conv_T[0],
@@ -617,6 +639,7 @@ void run_wav2vec(artalk_model* m, const float* audio, int c0, int n, float* out_
     stage_mark(m, s, PB_CONV);
     roctxRangePop();
     Range r_enc("artalk.wav2vec2.encoder");             // K4-K7: projection, pos-conv, 24 layers, final LN, pooling + SiLU
+    kbucket(m, KB_ENC);
     const int M = n * m->Ts;
     // hidden states use a 200-row stride per chunk, 199 valid.  The padding row is never read by a valid row; the LayerNorms store
     // it as zeros (LnArgs::junk_period), and the attention output's padding row is never written (zero since allocation), so
@@ -686,6 +709,7 @@ void run_style(artalk_model* m, const float* style_motion, int B, hipStream_t s,
     Workspace& w = m->ws;
     const int S = c.style_dim, L = c.style_len, M = B * L;
     Range r_style("artalk.style_encoder");
+    kbucket(m, KB_STYLE);
     if (style_motion && encode) {
         launch_style_input(style_motion, m->st_mean, m->st_std, w.s_in, B, s);
         linear(m, w.s_in, 128, m->st_proj_w, m->st_proj_b, w.s_h, S, M, S, 128, ACT_NONE, nullptr, s);
@@ -754,6 +778,7 @@ void run_reencode(artalk_model* m, int B, hipStream_t s) {
     Workspace& w = m->view ? *m->view : m->ws;
     const int H = c.vae_hidden, T = 100;
     Range r_re("artalk.vae.reencode_bsq");              // K16-K17: encoder, multi-scale BSQ, history features
+    kbucket(m, KB_REENC);
     audit(m, "vae.encoder.input(fp32 A)", -1, nullptr, w.enc_in, B * T, 128, 128, false, s, &m->ex.vae_enc_in);
     linear(m, w.enc_in, 128, m->enc.in_w, m->enc.in_b, w.vh, H, B * T, H, 128, ACT_LEAKY02, nullptr, s, 0, nullptr, m->ex.vae_enc_in);
     run_vae_stack(m, m->enc, B, T, 0, s);
@@ -766,6 +791,7 @@ void run_reencode(artalk_model* m, int B, hipStream_t s) {
 // Initial history of B clips (app/models.py:86-89) from the per-model cache (artalk_model::init_hist).
 int run_init_history(artalk_model* m, int B, hipStream_t s) {
     const artalk_config& c = m->cfg;
+    struct Restore { artalk_model* m; ~Restore() { kbucket(m, KB_OTHER); } } restore{m};
     Workspace& w = m->ws;
     artalk_model::InitHistory& ih = m->init_hist[m->precision == 1 ? 1 : 0];
     const long nb = (long)kNTok * c.code_dim, nf = 100L * c.code_dim * 4, nm = 180L * c.code_dim * 4;
@@ -809,6 +835,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s, int n_reencode = -1) 
     // format by their producers, which lets every block GEMM use the LDS-DMA kernels (gemm_p8_sm_kernel at these grid sizes)
     const int p8 = m->precision == 1 ? 1 : 0;
     // K/V of the 181 history tokens, once per layer (raw prev tokens, not modulated: app/transformer.py:68-70)
+    kbucket(m, KB_AR_MISC);
     tap_copy(m, TAP_PREV_IN, 0, w.prev_in, kNTok, kE, B, s);      // prev_attn_feat + prev_lvl_pos_embed (app/models.py:101, 2nd argument)
     roctxRangePushA("artalk.ar.history_kv");
     SiteExps& ex = m->ex;
@@ -841,6 +868,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s, int n_reencode = -1) 
                                                    "artalk.ar.scale_step3", "artalk.ar.scale_step4"};
     for (int p = 0; p < c.n_levels; ++p) {
         Range r_lv(kLevelName[p]);                       // K8-K14 of one scale step: 12 blocks, head, bits, next-scale features
+        kbucket(m, KB_LEVEL0 + p);
         const int pn = m->pn[p], off = m->off[p], M = B * pn;
         const RowMap amap = rowmap(pn, kNTok, off);            // rows of the AdaLN table for this level's tokens
         // AdaLN-modulated LayerNorm into w.xmod: block l's first (which = 0) / second (1) norm, or the head's (l = depth).  Each is
@@ -915,6 +943,7 @@ void run_chunk_body(artalk_model* m, int B, hipStream_t s, int n_reencode = -1) 
     // ---- VAE decode of [history | current] (bitwise_vae.py:105-113) ----
     const int H = c.vae_hidden;
     roctxRangePushA("artalk.vae.decode");               // K15
+    kbucket(m, KB_VAE_DEC);
     launch_dec_input(w.prev_fdec, w.fhat, w.bits, m->dec_pos, w.dec_x, B, s);
     audit(m, "vae.decoder.input(fp32 A)", -1, nullptr, w.dec_x, B * 200, c.code_dim, c.code_dim, false, s, &ex.vae_dec_in);
     linear(m, w.dec_x, c.code_dim, m->dec.in_w, m->dec.in_b, w.vh, H, B * 200, H, c.code_dim, ACT_LEAKY02, nullptr, s, 0, nullptr, ex.vae_dec_in);
@@ -954,9 +983,23 @@ Workspace clip_view(const artalk_model* m, int b0, int branch) {
 // for B >= 8 the batch is cut into two halves that run as parallel branches (stream s and m->side_stream; inside a capture this
 // becomes a fork/join in the hipGraph): one half's GPU-filling step overlaps the other half's latency-bound ones.
 int ensure_side_streams(artalk_model* m, int n);
+int body_branches(const artalk_model* m, int B);
 int run_chunk_body_split(artalk_model* m, int B, hipStream_t s, int n_next = -1) {
     if (n_next < 0 || n_next > B) n_next = B;
-    if (B < 8 || m->profiling == 2 || m->branches == 1 || m->audit || m->tap) { run_chunk_body(m, B, s, n_next); return ARTALK_OK; }
+    if (m->profiling == 3 && B >= 8 && m->branches != 1 && !m->audit && !m->tap) {
+        // kernel timer: the SAME clip groups (and therefore the same kernels, tiles and split-K factors) as the graphs replay, one
+        // after the other on one stream - the sums are then those of the production launches, without their overlap
+        const int NS = body_branches(m, B);
+        for (int h = 0; h < NS; ++h) {
+            const int lo = (int)((long)B * h / NS), hi = (int)((long)B * (h + 1) / NS);
+            Workspace v = clip_view(m, lo, h);
+            m->view = &v;
+            run_chunk_body(m, hi - lo, s, std::max(0, std::min(n_next - lo, hi - lo)));
+            m->view = nullptr;
+        }
+        return ARTALK_OK;
+    }
+    if (B < 8 || m->profiling >= 2 || m->branches == 1 || m->audit || m->tap) { run_chunk_body(m, B, s, n_next); return ARTALK_OK; }
     if (int rc = ensure_side_streams(m, 1)) return rc;
     const int B0 = (B + 1) / 2, B1 = B - B0;
     Workspace v0 = clip_view(m, 0, 0), v1 = clip_view(m, B0, 1);
@@ -1205,6 +1248,7 @@ void artalk_destroy(artalk_model* m) {
     (void)hipDeviceSynchronize();
     for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second.exec);
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : m->ktimer.pool) (void)hipEventDestroy(e);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     for (int i = 0; i < 3; ++i) {
         if (m->side_stream[i]) (void)hipStreamDestroy(m->side_stream[i]);
@@ -1355,7 +1399,7 @@ int artalk_reserve(artalk_model* m, int max_batch, int max_total_chunks) {
 int64_t artalk_workspace_bytes(const artalk_model* m) { return m ? m->ws.bytes : 0; }
 int64_t artalk_weight_bytes(const artalk_model* m) { return m ? m->weight_bytes : 0; }
 
-int artalk_set_profiling(artalk_model* m, int level) { if (!m || level < 0 || level > 2) return ARTALK_EINVAL; m->profiling = level; return ARTALK_OK; }
+int artalk_set_profiling(artalk_model* m, int level) { if (!m || level < 0 || level > 3) return ARTALK_EINVAL; m->profiling = level; return ARTALK_OK; }
 int artalk_set_precision(artalk_model* m, int mode) {
     if (!m || (mode != 0 && mode != 1)) return ARTALK_EINVAL;
     m->precision = mode;   // captured graphs are keyed by mode: switching costs nothing and keeps both sets
@@ -1561,6 +1605,10 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
     m->stream_B = 0;   // the batch call reuses the workspace that holds the streaming history
     HIPCHK(m, hipMemsetAsync(w.status, 0, 4 * sizeof(int), s));
     m->ev_used = 0; m->dom_events.clear(); m->marks.clear(); m->prof_stream = s;
+    // level 3: every kernel of this call is launched with its own start / stop events (kernels.h ARTALK_LAUNCH) - on this thread, for the
+    // duration of the call; the body then runs eagerly as ONE clip group, like level 2
+    struct TimerScope { bool on; TimerScope(artalk_model* x) : on(x->profiling == 3) { if (on) { x->ktimer.used = 0; x->ktimer.recs.clear(); x->ktimer.bucket = KB_OTHER; g_ktimer = &x->ktimer; } }
+                        ~TimerScope() { if (on) g_ktimer = nullptr; } } timer_scope(m);
     stage_mark(m, s, PB_OTHER);
     run_style(m, (style_motion_dev && has_style) ? style_motion_dev : nullptr, B, s, encode_style);
     stage_mark(m, s, PB_STYLE);
@@ -1575,12 +1623,13 @@ int artalk_infer(artalk_model* m, const float* audio_dev, int64_t audio_clip_str
         HIPCHK(m, hipMemcpy2DAsync(out_hist_bits_dev, (size_t)(maxch + 1) * bits_row, w.hist_bits, bits_row, bits_row, B,
                                    hipMemcpyDeviceToDevice, s));
     stage_mark(m, s, PB_VAE);
-    const bool graphs = m->use_graphs && m->profiling != 2 && !m->audit && !m->tap;
+    const bool graphs = m->use_graphs && m->profiling < 2 && !m->audit && !m->tap;
     // AdaLN table of a chunk index for all blocks + head: SiLU(cond) @ [W_0;...;W_11;W_head]^T, in line in front of the body that reads it.
     // (The table of chunk index j + 1 on a stream of its own beside body j was measured in round 4 and removed in round 5: the bodies slow
     // down by what the table GEMM takes, profiles/r04_ada_overlap_sweep.log.)
     auto ada_table = [&](int64_t j) {
         roctxRangePushA("artalk.ar.adaln_table");
+        kbucket(m, KB_ADA);
         linear(m, w.silu_cond + (long)base[j] * kNTok * kCond, kCond, m->ada_w, m->ada_b, w.ada, m->ada_n, Bj[j] * kNTok, m->ada_n, kCond,
                ACT_NONE, nullptr, s, m->precision == 1 ? LF_A_P8 : 0, nullptr, m->ex.silu_cond);
         roctxRangePop();
@@ -1770,6 +1819,26 @@ int artalk_get_profile(artalk_model* m, double* out, int n) {
     r[6] = ms(m->marks.front().second, m->marks.back().second);
     for (auto& d : m->dom_events) { r[7] += 1.0; r[8] += ms(d.first, d.first + 1); r[9] += d.second; }
     for (int i = 0; i < 10; ++i) out[i] = r[i];
+    return ARTALK_OK;
+}
+
+// Kernel-time budget of the last artalk_infer run at profiling level 3: out[b] = sum of the durations (ms) of the kernels launched in
+// bucket b - 0 style, 1 conv stack, 2 encoder, 3 AdaLN tables, 4 history K/V + glue, 5..9 scale steps 0..4, 10 VAE decode, 11 re-encode,
+// 12 other - and out[13] = number of kernels timed.  Durations are the dispatches' own begin / end timestamps (hipExtLaunchKernelGGL
+// events), i.e. without launch gaps: stage event time minus this sum is the time the stage's stream sat idle.  n >= 14.
+int artalk_get_kernel_sums(artalk_model* m, double* out, int n) {
+    if (!m || !out || n < KB_N + 1) return ARTALK_EINVAL;
+    if (m->ktimer.recs.empty()) return fail(m, ARTALK_ESTATE, "no kernel was timed (artalk_set_profiling(3) before artalk_infer)");
+    (void)hipSetDevice(m->device);
+    HIPCHK(m, hipDeviceSynchronize());
+    for (int i = 0; i <= KB_N; ++i) out[i] = 0.0;
+    for (const auto& r : m->ktimer.recs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, m->ktimer.pool[r.second], m->ktimer.pool[r.second + 1]) != hipSuccess) continue;
+        const int b = r.first >= 0 && r.first < KB_N ? r.first : KB_OTHER;
+        out[b] += t;
+        out[KB_N] += 1.0;
+    }
     return ARTALK_OK;
 }
 

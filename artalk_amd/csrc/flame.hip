@@ -123,14 +123,14 @@ __global__ __launch_bounds__(256) void flame_skin_kernel(const float* __restrict
 }
 
 void launch_flame_pose(const float* pose, float* rot, float* feat, int T, int ldf, hipStream_t s) {
-    hipLaunchKernelGGL(flame_pose_kernel, dim3((T * FJ + 127) / 128), dim3(128), 0, s, pose, rot, feat, T, ldf);
+    ARTALK_LAUNCH(flame_pose_kernel, dim3((T * FJ + 127) / 128), dim3(128), 0, s, pose, rot, feat, T, ldf);
 }
 void launch_flame_joints(const float* vs, const float* jreg, float* J, int T, int V, hipStream_t s) {
-    hipLaunchKernelGGL(flame_joints_kernel, dim3(T), dim3(256), 0, s, vs, jreg, J, V);
+    ARTALK_LAUNCH(flame_joints_kernel, dim3(T), dim3(256), 0, s, vs, jreg, J, V);
 }
 void launch_flame_skin(const float* vposed, const float* rot, const float* J, const int* parents, const float* weights, float* out,
                        int T, int V, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(flame_skin_kernel, dim3((V + 255) / 256, T), dim3(256), 0, s, vposed, rot, J, parents, weights, out, V, scale);
+    ARTALK_LAUNCH(flame_skin_kernel, dim3((V + 255) / 256, T), dim3(256), 0, s, vposed, rot, J, parents, weights, out, V, scale);
 }
 
 }  // namespace artalk

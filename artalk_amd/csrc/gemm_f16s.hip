@@ -64,7 +64,7 @@ void launch_pack_split(const float* w, unsigned int* out, long n, bool is_weight
     if (n <= 0) return;
     if (is_weight) status = nullptr;
     const long blocks = (n / 8 + 255) / 256;   // n % 8 == 0 (every packed tensor has an inner dimension that is a multiple of 32)
-    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, w, out, n, is_weight ? kWScale : p8_scale_of(p8_exp), status, p8_maxbits_of(p8_exp));
+    ARTALK_LAUNCH(pack_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, w, out, n, is_weight ? kWScale : p8_scale_of(p8_exp), status, p8_maxbits_of(p8_exp));
 }
 
 // AMODE 1: grouped positional-conv window gather (see gemm_f32.hip), grid.z = group, fp32 A only.
@@ -1877,15 +1877,15 @@ void launch_posconv_p8(const GemmArgs& g, int n_chunks, int T, int Ts, hipStream
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&posconv_p8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(posconv_p8_kernel, dim3(n_chunks * 16), dim3(512), lds, s, g, T, Ts);
+    ARTALK_LAUNCH(posconv_p8_kernel, dim3(n_chunks * 16), dim3(512), lds, s, g, T, Ts);
 }
 
 template <int BM, int BN, int STAGES>
 static void launch_p8_sm_cfg(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     const size_t lds = STAGES * (BM + BN) * 128;
-    if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_sm_kernel<BM, BN, STAGES, 1>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
-    else hipLaunchKernelGGL((gemm_p8_sm_kernel<BM, BN, STAGES, 0>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
+    if (g.graph_tag) ARTALK_LAUNCH((gemm_p8_sm_kernel<BM, BN, STAGES, 1>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
+    else ARTALK_LAUNCH((gemm_p8_sm_kernel<BM, BN, STAGES, 0>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
 }
 bool gemm_p8_sm_eligible(const GemmArgs& g) {
     return g.Wp != nullptr && g.a_packed && g.amode == 0 && g.batch == 1 && g.K % 32 == 0 && (g.lda % 8) == 0;
@@ -1899,16 +1899,16 @@ template <int STAGES>
 static void launch_p8_mid(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     gemm_p8_prepare();
-    if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_mid_kernel<STAGES, 1>), dim3(tiles, g.splitk), dim3(512), STAGES * 256 * 128, s, g);
-    else hipLaunchKernelGGL((gemm_p8_mid_kernel<STAGES, 0>), dim3(tiles, g.splitk), dim3(512), STAGES * 256 * 128, s, g);
+    if (g.graph_tag) ARTALK_LAUNCH((gemm_p8_mid_kernel<STAGES, 1>), dim3(tiles, g.splitk), dim3(512), STAGES * 256 * 128, s, g);
+    else ARTALK_LAUNCH((gemm_p8_mid_kernel<STAGES, 0>), dim3(tiles, g.splitk), dim3(512), STAGES * 256 * 128, s, g);
 }
 template <int BM, int BN, int WMW, int WNW, int STAGES, int BAR2>
 static void launch_p8_pp(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     gemm_p8_prepare();
     const size_t lds = STAGES * (BM + BN) * 128;
-    if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_pp_kernel<BM, BN, WMW, WNW, STAGES, BAR2, 1>), dim3(tiles, g.splitk), dim3(512), lds, s, g);
-    else hipLaunchKernelGGL((gemm_p8_pp_kernel<BM, BN, WMW, WNW, STAGES, BAR2, 0>), dim3(tiles, g.splitk), dim3(512), lds, s, g);
+    if (g.graph_tag) ARTALK_LAUNCH((gemm_p8_pp_kernel<BM, BN, WMW, WNW, STAGES, BAR2, 1>), dim3(tiles, g.splitk), dim3(512), lds, s, g);
+    else ARTALK_LAUNCH((gemm_p8_pp_kernel<BM, BN, WMW, WNW, STAGES, BAR2, 0>), dim3(tiles, g.splitk), dim3(512), lds, s, g);
 }
 // what gemm_p8_pp_kernel's 32-bit DMA offsets need: operands below 4 GiB
 bool gemm_p8_pp_ok(const GemmArgs& g) {
@@ -2006,11 +2006,11 @@ static void launch_p8_big(const GemmArgs& g, hipStream_t s) {
     const size_t lds = 2 * (64 * TM + 256) * 128 + 4096;
     const dim3 grid(tiles < cus ? tiles : cus);
     if (g.R) {
-        if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_big_kernel<TM, true, 1>), grid, dim3(512), lds, s, g);
-        else hipLaunchKernelGGL((gemm_p8_big_kernel<TM, true, 0>), grid, dim3(512), lds, s, g);
+        if (g.graph_tag) ARTALK_LAUNCH((gemm_p8_big_kernel<TM, true, 1>), grid, dim3(512), lds, s, g);
+        else ARTALK_LAUNCH((gemm_p8_big_kernel<TM, true, 0>), grid, dim3(512), lds, s, g);
     } else {
-        if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_big_kernel<TM, false, 1>), grid, dim3(512), lds, s, g);
-        else hipLaunchKernelGGL((gemm_p8_big_kernel<TM, false, 0>), grid, dim3(512), lds, s, g);
+        if (g.graph_tag) ARTALK_LAUNCH((gemm_p8_big_kernel<TM, false, 1>), grid, dim3(512), lds, s, g);
+        else ARTALK_LAUNCH((gemm_p8_big_kernel<TM, false, 0>), grid, dim3(512), lds, s, g);
     }
 }
 void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
@@ -2033,9 +2033,9 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
         gemm_p8_prepare();
         if (cfg == 7) launch_p8_big<4>(g, s); else launch_p8_big<5>(g, s);
     } else if (cfg == 13) {
-        hipLaunchKernelGGL((gemm_p8_256_kernel<0>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g);
+        ARTALK_LAUNCH((gemm_p8_256_kernel<0>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g);
     } else if (cfg == 17) {
-        hipLaunchKernelGGL((gemm_p8_256_kernel<6>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g);
+        ARTALK_LAUNCH((gemm_p8_256_kernel<6>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g);
     } else {
         // residual tiles deferred too (ARTALK_P8_RES_DEFER=0 finishes them at once; tests compare both): 16 KiB more LDS, still two
         // workgroups per CU
@@ -2044,8 +2044,8 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
         if (g.res_lds) gemm_p8_prepare();
         const size_t lds = 2 * 256 * 128 + (g.res_lds ? 16384 : 0);
         const int slots = 2 * p8_cus_of(g);      // two workgroups per CU
-        if (g.graph_tag) hipLaunchKernelGGL((gemm_p8_2wgp_kernel<1>), dim3(t128 < slots ? t128 : slots), dim3(256), lds, s, g);
-        else hipLaunchKernelGGL((gemm_p8_2wgp_kernel<0>), dim3(t128 < slots ? t128 : slots), dim3(256), lds, s, g);
+        if (g.graph_tag) ARTALK_LAUNCH((gemm_p8_2wgp_kernel<1>), dim3(t128 < slots ? t128 : slots), dim3(256), lds, s, g);
+        else ARTALK_LAUNCH((gemm_p8_2wgp_kernel<0>), dim3(t128 < slots ? t128 : slots), dim3(256), lds, s, g);
     }
 }
 // 0: persistent two-workgroup 128x128 kernel, 1 / 2: persistent big-tile kernel with 256x256 / 320x256 tiles.  A cost model picks the
@@ -2079,13 +2079,13 @@ static void launch_f16s_cfg(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     const size_t lds = 2 * (BM + BN) * 144;
     if (g.amode == 1) {
-        hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 0, 0, 1>), dim3(tiles, 1, g.batch), dim3(256), lds, s, g);
+        ARTALK_LAUNCH((gemm_f16s_kernel<BM, BN, WM, WN, 0, 0, 1>), dim3(tiles, 1, g.batch), dim3(256), lds, s, g);
     } else if (g.a_packed) {
-        if (g.graph_tag) hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 1, 1>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
-        else hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 1, 0>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
+        if (g.graph_tag) ARTALK_LAUNCH((gemm_f16s_kernel<BM, BN, WM, WN, 1, 1>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
+        else ARTALK_LAUNCH((gemm_f16s_kernel<BM, BN, WM, WN, 1, 0>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
     } else {
-        if (g.graph_tag) hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 0, 1>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
-        else hipLaunchKernelGGL((gemm_f16s_kernel<BM, BN, WM, WN, 0, 0>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
+        if (g.graph_tag) ARTALK_LAUNCH((gemm_f16s_kernel<BM, BN, WM, WN, 0, 1>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
+        else ARTALK_LAUNCH((gemm_f16s_kernel<BM, BN, WM, WN, 0, 0>), dim3(tiles, g.splitk), dim3(256), lds, s, g);
     }
 }
 

@@ -161,11 +161,11 @@ static void launch_cfg(const GemmArgs& g, hipStream_t s) {
     const size_t lds = 2 * (BM + BN) * (BK + 4) * sizeof(float);
     dim3 grid(tiles, g.splitk, g.batch);
     if (g.amode == 0 && g.graph_tag && BM == 64 && BN == 64)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, 0, 1>), grid, dim3(256), lds, s, g);
+        ARTALK_LAUNCH((gemm_f32_kernel<BM, BN, WM, WN, BK, 0, 1>), grid, dim3(256), lds, s, g);
     else if (g.amode == 0)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, 0>), grid, dim3(256), lds, s, g);
+        ARTALK_LAUNCH((gemm_f32_kernel<BM, BN, WM, WN, BK, 0>), grid, dim3(256), lds, s, g);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, 1>), grid, dim3(256), lds, s, g);
+        ARTALK_LAUNCH((gemm_f32_kernel<BM, BN, WM, WN, BK, 1>), grid, dim3(256), lds, s, g);
 }
 
 // Tile choice, from tools/gemm_bench.py on MI355X (profiles/r01_gemm_bench.log).  A register-only MFMA loop sustains
@@ -254,12 +254,12 @@ void launch_splitk_reduce(const GemmArgs& g, hipStream_t s) {
     const long blocks = (total / 4 + 255) / 256;
     const dim3 grid((unsigned)(blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048));
     switch (g.splitk) {
-        case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, grid, dim3(256), 0, s, g); break;
-        case 3: hipLaunchKernelGGL(splitk_reduce_kernel<3>, grid, dim3(256), 0, s, g); break;
-        case 4: hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, s, g); break;
-        case 6: hipLaunchKernelGGL(splitk_reduce_kernel<6>, grid, dim3(256), 0, s, g); break;
-        case 8: hipLaunchKernelGGL(splitk_reduce_kernel<8>, grid, dim3(256), 0, s, g); break;
-        default: hipLaunchKernelGGL(splitk_reduce_kernel<0>, grid, dim3(256), 0, s, g); break;
+        case 2: ARTALK_LAUNCH(splitk_reduce_kernel<2>, grid, dim3(256), 0, s, g); break;
+        case 3: ARTALK_LAUNCH(splitk_reduce_kernel<3>, grid, dim3(256), 0, s, g); break;
+        case 4: ARTALK_LAUNCH(splitk_reduce_kernel<4>, grid, dim3(256), 0, s, g); break;
+        case 6: ARTALK_LAUNCH(splitk_reduce_kernel<6>, grid, dim3(256), 0, s, g); break;
+        case 8: ARTALK_LAUNCH(splitk_reduce_kernel<8>, grid, dim3(256), 0, s, g); break;
+        default: ARTALK_LAUNCH(splitk_reduce_kernel<0>, grid, dim3(256), 0, s, g); break;
     }
 }
 
@@ -337,11 +337,11 @@ bool splitk_reduce_ln_eligible(const GemmArgs& g, const LnArgs& ln) {
 void launch_splitk_reduce_ln(const GemmArgs& g, const LnArgs& ln, hipStream_t s) {
     const dim3 grid((g.M + 3) / 4);
     switch (g.splitk) {
-        case 2: hipLaunchKernelGGL(splitk_reduce_ln768_kernel<2>, grid, dim3(256), 0, s, g, ln); break;
-        case 3: hipLaunchKernelGGL(splitk_reduce_ln768_kernel<3>, grid, dim3(256), 0, s, g, ln); break;
-        case 4: hipLaunchKernelGGL(splitk_reduce_ln768_kernel<4>, grid, dim3(256), 0, s, g, ln); break;
-        case 6: hipLaunchKernelGGL(splitk_reduce_ln768_kernel<6>, grid, dim3(256), 0, s, g, ln); break;
-        default: hipLaunchKernelGGL(splitk_reduce_ln768_kernel<8>, grid, dim3(256), 0, s, g, ln); break;
+        case 2: ARTALK_LAUNCH(splitk_reduce_ln768_kernel<2>, grid, dim3(256), 0, s, g, ln); break;
+        case 3: ARTALK_LAUNCH(splitk_reduce_ln768_kernel<3>, grid, dim3(256), 0, s, g, ln); break;
+        case 4: ARTALK_LAUNCH(splitk_reduce_ln768_kernel<4>, grid, dim3(256), 0, s, g, ln); break;
+        case 6: ARTALK_LAUNCH(splitk_reduce_ln768_kernel<6>, grid, dim3(256), 0, s, g, ln); break;
+        default: ARTALK_LAUNCH(splitk_reduce_ln768_kernel<8>, grid, dim3(256), 0, s, g, ln); break;
     }
 }
 int gemm_tile_count(const GemmArgs& g, bool f16s) {
@@ -506,18 +506,18 @@ __global__ __launch_bounds__(256) void mfma_f16_peak_rnd_kernel(float* out, int 
 // nacc 16 / 17: the fp16 kernels above (32x32x16 / 16x16x32)
 double launch_mfma_f32_peak(float* out, int blocks, int iters, int nacc, hipStream_t s) {
     if (nacc == 16 || nacc == 17) {
-        if (nacc == 16) hipLaunchKernelGGL(mfma_f16_peak_kernel<0>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
-        else hipLaunchKernelGGL(mfma_f16_peak_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
+        if (nacc == 16) ARTALK_LAUNCH(mfma_f16_peak_kernel<0>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
+        else ARTALK_LAUNCH(mfma_f16_peak_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
         // per iteration and wave: 32 MFMAs of 32x32x16 (32768 flops each) or 64 of 16x16x32 (16384 flops each)
         return (double)blocks * 4 * iters * 32.0 * (32.0 * 32 * 16 * 2);
     }
     if (nacc == 18 || nacc == 19) {      // the fp16 shapes on changing pseudo-random operands
-        if (nacc == 18) hipLaunchKernelGGL(mfma_f16_peak_rnd_kernel<0>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
-        else hipLaunchKernelGGL(mfma_f16_peak_rnd_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
+        if (nacc == 18) ARTALK_LAUNCH(mfma_f16_peak_rnd_kernel<0>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
+        else ARTALK_LAUNCH(mfma_f16_peak_rnd_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
         return (double)blocks * 4 * iters * 32.0 * (32.0 * 32 * 16 * 2);
     }
-    if (nacc == 1) hipLaunchKernelGGL(mfma_f32_peak_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
-    else hipLaunchKernelGGL(mfma_f32_peak_kernel<4>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
+    if (nacc == 1) ARTALK_LAUNCH(mfma_f32_peak_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
+    else ARTALK_LAUNCH(mfma_f32_peak_kernel<4>, dim3(blocks), dim3(256), 0, s, out, iters, 0.37f);
     return (double)blocks * 4 /*waves*/ * iters * 32.0 /*mfma per iter*/ * (32.0 * 32 * 2 * 2);
 }
 }  // namespace artalk

@@ -6,7 +6,31 @@
 #include <climits>
 #include <cstdint>
 
+#include <hip/hip_ext.h>
+#include <utility>
+#include <vector>
+
 namespace artalk {
+
+// ---- per-kernel timing without a profiler (artalk_set_profiling level 3; bench.py `budget_ms`).  While a KernelTimer is active on the
+// launching thread, every launch of the library goes through hipExtLaunchKernelGGL with a start / stop event pair: the events carry
+// the dispatch's own begin / end timestamps (what rocprofv3 --kernel-trace reports), so their difference is the kernel's duration
+// without the gap to its neighbours.  Durations are summed per bucket (a stage of the path, a scale step of the body).
+struct KernelTimer {
+    int bucket = 0;
+    std::vector<hipEvent_t> pool; size_t used = 0;
+    std::vector<std::pair<int, size_t>> recs;      // (bucket, index of the start event; the stop event is the next one)
+};
+extern thread_local KernelTimer* g_ktimer;          // engine.hip; null = plain launches
+bool ktimer_events(hipEvent_t* e0, hipEvent_t* e1);  // next event pair of the active timer (false: none active)
+#define ARTALK_LAUNCH(kernel, grid, block, lds, stream, ...)                                                          \
+    do {                                                                                                              \
+        hipEvent_t kt_e0_ = nullptr, kt_e1_ = nullptr;                                                                \
+        if (artalk::g_ktimer && artalk::ktimer_events(&kt_e0_, &kt_e1_))                                              \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, kt_e0_, kt_e1_, 0, __VA_ARGS__);                  \
+        else                                                                                                          \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                        \
+    } while (0)
 
 // row(m) = (m / rpb) * bstride + off + (m % rpb).  Identity when rpb == INT_MAX.
 // Lets one GEMM read/write compact [B*L] rows and per-clip strided storage (KV cache, AdaLN table).

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
 template <int D, int RPW>
 static void launch_ln(const LnArgs& a, hipStream_t s) {
     const int rows_per_block = 4 * RPW;
-    hipLaunchKernelGGL((layernorm_kernel<D, RPW>), dim3((a.M + rows_per_block - 1) / rows_per_block), dim3(256), 0, s, a);
+    ARTALK_LAUNCH((layernorm_kernel<D, RPW>), dim3((a.M + rows_per_block - 1) / rows_per_block), dim3(256), 0, s, a);
 }
 
 void launch_layernorm(const LnArgs& a, hipStream_t s) {

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(1024) void audio_normalize_kernel(const float* __re
 
 void launch_audio_normalize(const float* audio, const long* src_off, float* xnorm, int n_chunks, int n, hipStream_t s) {
     if (n_chunks <= 0) return;
-    hipLaunchKernelGGL(audio_normalize_kernel, dim3(n_chunks), dim3(1024), 0, s, audio, src_off, xnorm, n);
+    ARTALK_LAUNCH(audio_normalize_kernel, dim3(n_chunks), dim3(1024), 0, s, audio, src_off, xnorm, n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
 void launch_conv0(const float* xnorm, int n, const float* w, const float* bias, const float* lnw, const float* lnb,
                   float* Y, int n_chunks, int T, int row_stride, hipStream_t s, int out_p8, int* status, int p8_exp) {
     if (n_chunks <= 0) return;
-    hipLaunchKernelGGL(conv0_kernel, dim3(128, n_chunks), dim3(256), 0, s, xnorm, n, w, bias, lnw, lnb, Y, T, row_stride, status, out_p8, p8_exp);
+    ARTALK_LAUNCH(conv0_kernel, dim3(128, n_chunks), dim3(256), 0, s, xnorm, n, w, bias, lnw, lnb, Y, T, row_stride, status, out_p8, p8_exp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -150,7 +150,7 @@ void launch_pool_silu(const float* X, int x_tstride, int T, float* Y, int n_chun
     lv.n = n_lvls;
     int ntok = 0;
     for (int i = 0; i < 8; ++i) { lv.pn[i] = i < n_lvls ? patch_nums[i] : 1 << 30; if (i < n_lvls) ntok += patch_nums[i]; }
-    hipLaunchKernelGGL(pool_silu_kernel, dim3(ntok, n_chunks), dim3(256), 0, s, X, x_tstride, T, Y, lv, ntok, D, out_p8, status, p8_exp);
+    ARTALK_LAUNCH(pool_silu_kernel, dim3(ntok, n_chunks), dim3(256), 0, s, X, x_tstride, T, Y, lv, ntok, D, out_p8, status, p8_exp);
 }
 
 }  // namespace artalk
@@ -184,6 +184,6 @@ void launch_resample_mean(const float* x, int nch, int n, const float* taps, int
                           hipStream_t s) {
     if (n_out <= 0) return;
     const int blocks = (n_out + 255) / 256;
-    hipLaunchKernelGGL(resample_mean_kernel, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, s, x, nch, n, taps, orig, nw, width, out, n_out);
+    ARTALK_LAUNCH(resample_mean_kernel, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, s, x, nch, n, taps, orig, nw, width, out, n_out);
 }
 }  // namespace artalk

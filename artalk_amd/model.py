@@ -226,7 +226,8 @@ class BitwiseARModel:
         return int(capi.lib().artalk_weight_bytes(self._h))
 
     def set_profiling(self, level: int):
-        """0 off, 1 light (graphs on, eager launches bracketed), 2 full (graphs off)."""
+        """0 off, 1 light (graphs on, eager launches bracketed), 2 full (graphs off), 3 kernel timer (graphs off, one clip group,
+        every launch timed: ``get_kernel_sums``)."""
         capi.lib().artalk_set_profiling(self._h, int(level))
 
     def set_precision(self, mode):
@@ -294,6 +295,15 @@ class BitwiseARModel:
             raise RuntimeError("artalk_get_profile failed: " + self._err())
         keys = ["style_ms", "w2v_conv_ms", "w2v_encoder_ms", "ada_ms", "ar_ms", "vae_ms", "total_ms",
                 "dom_launches", "dom_ms", "dom_flop"]
+        return dict(zip(keys, list(out)))
+
+    def get_kernel_sums(self):
+        """Summed kernel durations (ms) per bucket of the last call made at ``set_profiling(3)`` (artalk_get_kernel_sums)."""
+        out = (C.c_double * 14)()
+        if capi.lib().artalk_get_kernel_sums(self._h, out, 14) != capi.OK:
+            raise RuntimeError("artalk_get_kernel_sums failed: " + self._err())
+        keys = ["style", "w2v_conv", "w2v_encoder", "ada", "ar_history_kv", "level0", "level1", "level2", "level3", "level4", "vae_decode",
+                "reencode", "other", "kernels"]
         return dict(zip(keys, list(out)))
 
     # ------------------------------------------------------------------ style-clip cache (SURVEY.md 8f rank 4)

@@ -283,6 +283,33 @@ def main():
     prof = model.get_profile()       # numbers of the last timed step
     model.set_profiling(0)
 
+    # Kernel-time budget per stage without a profiler: one more, untimed pass at profiling level 3 - graphs off, the
+    # same clip groups one after the other, every launch with its own start / stop events (hipExtLaunchKernelGGL: the dispatch's begin /
+    # end timestamps) - gives the summed kernel durations per stage; next to the stages' event times of the timed, pipelined run the
+    # difference is the time a stage's stream sat idle between kernels (single-stream stages), or - for the body, whose two clip groups
+    # replay concurrently - how much of the kernel time overlapped.
+    budget = None
+    if world == 1 and not args.no_alt_mode:
+        model.set_profiling(3)
+        model.inference_batch(dev_audio)
+        torch.cuda.synchronize()
+        ks = model.get_kernel_sums()
+        model.set_profiling(0)
+        body = sum(ks[k] for k in ("ar_history_kv", "level0", "level1", "level2", "level3", "level4", "vae_decode", "reencode"))
+        budget = {
+            "w2v_conv": {"event_ms": round(prof["w2v_conv_ms"], 2), "kernel_sum_ms": round(ks["w2v_conv"], 2)},
+            "w2v_encoder": {"event_ms": round(prof["w2v_encoder_ms"], 2), "kernel_sum_ms": round(ks["w2v_encoder"], 2)},
+            "ada": {"event_ms": round(prof["ada_ms"], 2), "kernel_sum_ms": round(ks["ada"], 2)},
+            "body": {"event_ms": round(prof["ar_ms"] + prof["vae_ms"], 2), "kernel_sum_ms": round(body, 2),
+                     "per_part_kernel_sum_ms": {k: round(ks[k], 3) for k in ("ar_history_kv", "level0", "level1", "level2", "level3", "level4", "vae_decode", "reencode")},
+                     "note": "kernel sums over both clip groups and all chunk indices; the groups' graphs replay concurrently, so event < sum = overlap"},
+            "other_kernel_sum_ms": round(ks["style"] + ks["other"], 3), "kernels_timed": int(ks["kernels"]),
+            "how": "event_ms: HIP events between the stage marks of the timed (pipelined, graph) step; kernel_sum_ms: sum of per-dispatch begin/end "
+                   "timestamps (hipExtLaunchKernelGGL events) of an extra eager pass over the same batch",
+        }
+        for k in ("w2v_conv", "w2v_encoder", "ada"):
+            budget[k]["idle_ms"] = round(budget[k]["event_ms"] - budget[k]["kernel_sum_ms"], 2)
+
     rc = 0
     if rank == 0:
         total_frames = args.steps * B * frames_per_clip * world
@@ -377,6 +404,7 @@ def main():
             "algorithmic_tflops": round(value * GFLOP_PER_FRAME / 1e3, 2),
             "stages_ms": {k: round(prof[k], 2) for k in ("style_ms", "w2v_conv_ms", "w2v_encoder_ms", "ada_ms", "ar_ms", "vae_ms", "total_ms")},
             "roofline": roofline,
+            "budget_ms": budget,
             "parity": parity,
             "load_s": round(t_load, 1),
         }

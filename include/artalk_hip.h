@@ -147,6 +147,11 @@ int artalk_savgol(artalk_model* m, const float* in_dev, float* out_dev, int T, v
  *   conv1-6 and the AdaLN tables; f32 mode: the 128x128-tile fp32 MFMA GEMM)  out[8] their summed ms  out[9] their summed FLOP */
 int artalk_set_profiling(artalk_model* m, int level);
 int artalk_get_profile(artalk_model* m, double* out, int n);
+/* Kernel-time budget without a profiler: after an artalk_infer at profiling level 3 (graphs off, one clip group, every launch carries its
+ * own start / stop events), out[b] = summed kernel durations (ms) per bucket - 0 style, 1 conv stack, 2 encoder, 3 AdaLN tables,
+ * 4 history K/V + glue, 5..9 scale steps 0..4, 10 VAE decode, 11 re-encode, 12 other - and out[13] = kernels timed (n >= 14).
+ * bench.py reports it next to the stages' event times as `budget_ms`. */
+int artalk_get_kernel_sums(artalk_model* m, double* out, int n);
 /* GEMM arithmetic: 0 (default) = exact fp32 on v_mfma_f32_32x32x2_f32; 1 = "f16x3": every fp32 operand split into two
  * fp16 values (22 significand bits), three fp16 MFMA products accumulated in fp32 - fp32-class accuracy (parity tests run in
  * both modes) at 5.3x the matrix-core rate; the logit / code heads stay on the fp32 path in both modes. */

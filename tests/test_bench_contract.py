@@ -31,6 +31,10 @@ def test_committed_bench_line_keeps_the_contract(path):
     c = d["config"]
     rate = d["n_gpus"] * c["clips_per_gpu"] * c["frames_per_clip"] / (d["ms_per_step"] * 1e-3)
     assert abs(rate - d["value"]) / d["value"] < 2e-3
+    if "budget_ms" in d and d["budget_ms"]:      # (round 5 on) kernel-sum beside event time per stage
+        bm = d["budget_ms"]
+        for k in ("w2v_conv", "w2v_encoder", "ada", "body"):
+            assert bm[k]["event_ms"] > 0 and bm[k]["kernel_sum_ms"] > 0, k
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
