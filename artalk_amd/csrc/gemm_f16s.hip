@@ -2031,6 +2031,35 @@ void launch_gemm_p8(const GemmArgs& g0, hipStream_t s) {
     if (cfg == 8 && !epi_vec_host(g)) cfg = 13;     // (no launch of the path gets here: every large-grid result is 16-byte aligned)
     if (cfg == 7 || cfg == 12) {
         gemm_p8_prepare();
+        // Round quantisation, the dispatch-only answer (round 5): a launch of 320-row tiles whose LAST round is partial
+        // goes out as two launches when the rows of that round fit ONE round of 256-row tiles - whole rounds of 320 x 256 first, then the
+        // remaining rows as 256 x 256 tiles (0.8 of a round's time).  With the shapes of batch 32 that is the encoder's FFN-in GEMM only
+        // (960 tiles = 3.75 rounds -> 768 tiles + 240 tiles of 256 rows: 3.8 rounds of time instead of 4); q|k|v (2.81 rounds) has no such
+        // split: 504 + 276 tiles, the second launch would spill into a second round.  Row ranges are independent and an element's K order
+        // does not depend on its tile: bit-identical.  MEASURED, NO GAIN (same box, three alternating pairs, profiles/r05_split2_ab.log:
+        // encoder 36.08 / 36.01 / 36.00 ms without, 36.03 / 36.09 / 35.98 ms with): in the partial last round of the single launch a quarter
+        // of the CUs are idle and the power-managed clock of the others rises, which already recovers most of what
+        // the quantisation costs on paper (5 % of the launch).  Off by default; ARTALK_P8_SPLIT2=1 switches it on (A/B).
+        static const int split2 = getenv("ARTALK_P8_SPLIT2") ? atoi(getenv("ARTALK_P8_SPLIT2")) : 0;
+        if (cfg == 12 && split2 && g0.force_cfg < 0 && g.cmap.rpb == INT_MAX && !g.gate) {
+            const int cus = p8_cus_of(g), tn = (g.N + 255) / 256, tm5 = (g.M + 319) / 320;
+            const int tiles5 = tm5 * tn, full = tiles5 / cus * cus;
+            if (full > 0 && tiles5 > full) {
+                const int rows1 = full / tn;                       // row tiles of the first launch (whole rounds or a little less)
+                const int M1 = rows1 * 320, M2 = g.M - M1;
+                const int tiles2 = ((M2 + 255) / 256) * tn;
+                const double t_one = std::ceil((double)tiles5 / cus), t_two = std::ceil((double)rows1 * tn / cus) + 0.8 * std::ceil((double)tiles2 / cus) + 0.04;
+                if (rows1 > 0 && M2 > 0 && tiles2 <= cus && t_two < t_one) {
+                    GemmArgs a = g, b = g;
+                    a.M = M1;
+                    b.M = M2; b.A = g.A + (long)M1 * g.lda; b.C = g.C + (long)M1 * g.ldc;
+                    if (g.R) b.R = g.R + (long)M1 * g.ldr;
+                    launch_p8_big<5>(a, s);
+                    launch_p8_big<4>(b, s);
+                    return;
+                }
+            }
+        }
         if (cfg == 7) launch_p8_big<4>(g, s); else launch_p8_big<5>(g, s);
     } else if (cfg == 13) {
         ARTALK_LAUNCH((gemm_p8_256_kernel<0>), dim3(t256sq), dim3(512), 8 * 64 * 68 * 4, s, g);

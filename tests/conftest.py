@@ -222,6 +222,7 @@ def assert_clip_parity(tag, precision, out, bits, hist, gout, gbits, ghist, logi
         gout, gbits, ghist, logit_margin, hist_margin = a["out"], a["bits"], a["hist_bits"], a["logit_margin"], a["hist_margin"]
         good, diff = decision_parity(bits, hist, gbits, ghist, logit_margin, hist_margin)
     assert_clip_parity.last_rounding_level = stages
+    assert_clip_parity.last_expected_out = gout      # the reference golden's codes, or the forced-decision continuation's the clip was held to
     good = min(good, n_chunks)
     n = min(good * 100, gout.shape[0])
     err = float(np.abs(out[:n] - gout[:n]).max()) if n else 0.0
@@ -248,6 +249,7 @@ def assert_clip_parity(tag, precision, out, bits, hist, gout, gbits, ghist, logi
 
 
 assert_clip_parity.last_rounding_level = 0
+assert_clip_parity.last_expected_out = None
 
 
 def load_alt(name):

@@ -94,12 +94,14 @@ def test_streaming_against_reference_golden(case, precision):
     spc = cfg.samples_per_chunk
     try:
         # the expected codes are the reference golden's - unless the one-shot call of this clip follows a rounding-level flip (judged
-        # there against the forced-decision continuation, conftest.assert_clip_parity): then its codes are, and streaming must equal them
+        # there against the forced-decision continuation, conftest.assert_clip_parity): then they are that CONTINUATION's codes, i.e.
+        # what the reference's arithmetic (the pinned CPU oracle) gives with the decision inverted - not this library's own batch output
         want = g["out"]
         batch = m.inference_batch([audio], [style], return_aux=True)[0].cpu().numpy()
         golden_parity(case, precision, batch, m.last_aux, g, inputs=(name, audio, style))
         if assert_clip_parity.last_rounding_level:
-            want = batch
+            want = assert_clip_parity.last_expected_out
+            assert want is not None and want.shape == g["out"].shape
         m.stream_begin(1, [style])
         got, frames = [], []
         for j in range(n_chunks):
