@@ -35,7 +35,7 @@ GFLOP_PER_FRAME = 2.159          # algorithmic work with KV cache, BASELINE.md s
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
 SUSTAINED_F16_MFMA_TFLOPS = 1745.0   # measured: register-only v_mfma_f32_32x32x16_f16 loop whose operands change from MFMA to MFMA holds 1.67-1.70 GHz (profiles/r03_mfma_f16_peak.log)
-PMC_TRAFFIC_FILE = "profiles/r04_pmc_traffic.json"      # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
+PMC_TRAFFIC_FILE = "profiles/r05_pmc_traffic.json"      # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
 MODES = {
     # precision -> (dtype string, dominant kernel symbol prefix in the PMC file, description, peak TF/s of ALGORITHMIC flops, note)
     "f32": ("f32", "gemm_f32_kernel<128, 128, 2, 2, 16, 0, 0>",

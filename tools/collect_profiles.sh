@@ -1,7 +1,7 @@
 # Collects everything kept under profiles/ for a round: run on the GPU box as
 #   gpurun -- 'bash tools/collect_profiles.sh r02'   (outputs under gpurun_out/<round>/, then copied into profiles/ by hand)
 set -e
-R=${1:-r04}
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 rm -rf $O && mkdir -p $O
@@ -48,4 +48,7 @@ bash tools/pmc_mfma_bench.sh $R > /dev/null 2>&1 || echo "mfma pmc failed"
 cat $O/mfma_util_per_instantiation.log
 echo "== P8 headroom"
 timeout -k 10 200 python tools/p8_headroom.py $O/p8_headroom.json 2>&1 | grep -v amdgpu.ids | tail -14
+ls $O
+echo "== P8 headroom, heavy profile, after the calibration pass (per-site scales)"
+timeout -k 10 300 python tools/p8_headroom.py $O/p8_headroom_heavy.json --profile heavy --calibrate 2>&1 | grep -v amdgpu.ids | tail -14
 ls $O

@@ -3,7 +3,7 @@
 #   clock = GRBM_GUI_ACTIVE / 8 / duration        busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8)
 # usage (GPU box): bash tools/pmc_mfma_bench.sh r04      -> gpurun_out/r04/mfma_util_per_instantiation.log
 set -e
-R=${1:-r04}
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 mkdir -p $O
@@ -13,7 +13,7 @@ done
 python3 - $O <<'PY' | tee $O/mfma_util_per_instantiation.log
 import csv, glob, collections, sys
 O=sys.argv[1]
-KERNELS=("gemm_p8_big", "gemm_p8_mid", "gemm_p8_sm_kernel<64, 64, 4", "gemm_p8_2wgp", "attention_f16_pp", "attention_f16_wide_ar", "posconv_p8")      # grids are reported in units of 512 threads
+KERNELS=("gemm_p8_big", "gemm_p8_mid", "gemm_p8_pp", "gemm_p8_sm_kernel<64, 64, 4", "gemm_p8_2wgp", "attention_f16_pp", "attention_f16_wide_ar", "posconv_p8")      # grids are reported in units of 512 threads
 val=collections.defaultdict(lambda: collections.defaultdict(list)); dur=collections.defaultdict(list)
 def key(r, gx): return (r["Kernel_Name"].split("(")[0].replace("void artalk::",""), int(gx))
 for c in ("SQ_VALU_MFMA_BUSY_CYCLES","GRBM_GUI_ACTIVE"):
