@@ -1213,7 +1213,8 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
     bool ok = c.n_levels == 5 && c.code_dim == 32 && c.motion_dim == 106 && c.vae_hidden == 512 && c.w2v_hidden == kCond &&
               c.w2v_conv_dim == 512 && c.w2v_n_conv >= 2 && c.w2v_n_conv <= 8 && c.ar_heads * 64 == kE && c.vae_heads * 64 == c.vae_hidden &&
               c.w2v_heads * 64 == c.w2v_hidden && c.style_dim == 128 && c.style_heads * 32 == c.style_dim && c.style_len == 50 &&
-              c.w2v_conv_kernel[0] == 10 && c.w2v_conv_stride[0] == 5 && c.w2v_ffn % 32 == 0 && c.style_ffn % 32 == 0;
+              c.w2v_conv_kernel[0] == 10 && c.w2v_conv_stride[0] == 5 && c.w2v_ffn % 32 == 0 && c.style_ffn % 32 == 0 &&
+              c.w2v_layers >= 1 && c.w2v_layers <= 64 && c.ar_depth >= 1 && c.ar_depth <= 32 && c.vae_depth >= 1 && c.vae_depth <= 16;      // (SiteExps tables)
     for (int i = 0; ok && i < 5; ++i) ok = c.patch_nums[i] == want_pn[i];
     if (!ok) { g_create_error = "unsupported configuration (kernels are specialised for assets/config.json + XLS-R-300M widths)"; return ARTALK_EINVAL; }
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return ARTALK_EHIP; }
