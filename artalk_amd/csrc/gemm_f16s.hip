@@ -1379,8 +1379,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_pp_kernel(const GemmArgs g) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     f16x8 ah[2][TMW], al[2][TMW], bh[2][TNW], bl[2][TNW];      // all fragments of one K step: [kb][tile]
-    constexpr int NRD_KB = 2 * (TMW + TNW);                       // ds_read_b128 per k block
-    static_assert(2 * NRD_KB <= 15 || true, "");
+    constexpr int NRD_KB = 2 * (TMW + TNW);                       // ds_read_b128 per k block (lgkmcnt is a 4-bit counter: with 16 reads of a phase in flight the 16th waits at issue)
     // LOAD phase of K step k: the pieces of stage k + S - 1 first (a Y wave's pieces have three phases to land, an X wave's four), then
     // every fragment of stage k, k block 0 first
     // (timing builds, results wrong: PP_ABL_NOMFMA one MFMA of a phase's 6 TMW TNW, PP_ABL_NODMA no DMA behind the prologue, PP_ABL_NOLDS

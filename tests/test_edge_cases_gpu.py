@@ -337,3 +337,39 @@ def test_graph_cache_is_bounded_for_ragged_batches():
         m.inference_batch([audios[i]], None, return_aux=True)
         assert torch.equal(m.last_aux["bits"][0].cpu(), bits[i]), f"clip {i}: ragged-batch decisions differ from the single run"
     assert m.status() == 0
+
+
+def test_kernel_timer_budget_matches_the_graph_path():
+    """artalk_set_profiling(3) (bench.py `budget_ms`): every launch goes through hipExtLaunchKernelGGL with its own start / stop events and
+    the durations are summed per stage / scale step (artalk_get_kernel_sums).  The pass runs the SAME clip groups eagerly, one after the
+    other: its results must be bit-identical to the graph replay's, every stage must have been timed, and the sums must be plausible
+    (positive, the encoder's above the conv stack's on this model, kernels counted)."""
+    from artalk_amd.synth import synth_audio
+    m = get_gpu_model("tiny")
+    m.set_precision("f16x3")
+    try:
+        audios = [torch.from_numpy(synth_audio(700 + i, 8.0)) for i in range(10)]
+        want = [o.clone() for o in m.inference_batch(audios)]
+        m.set_profiling(3)
+        got = m.inference_batch(audios)
+        ks = m.get_kernel_sums()
+        m.set_profiling(0)
+        for a, b in zip(want, got):
+            assert torch.equal(a, b), "the timed eager pass differs from the graph replay"
+        for k in ("w2v_conv", "w2v_encoder", "ada", "ar_history_kv", "level0", "level1", "level2", "level3", "level4", "vae_decode", "reencode"):
+            assert ks[k] > 0.0, (k, ks)
+        assert ks["kernels"] > 500 and ks["w2v_encoder"] < 1000.0 and ks["level4"] > ks["level0"] * 0.5
+        again = m.inference_batch(audios)          # back on the graph path
+        for a, b in zip(want, again):
+            assert torch.equal(a, b)
+        with pytest.raises(RuntimeError):
+            m.set_profiling(0)
+            mm = get_gpu_model("tiny")
+            from artalk_amd import capi
+            import ctypes as C
+            out = (C.c_double * 4)()
+            if capi.lib().artalk_get_kernel_sums(mm._h, out, 4) != capi.OK:      # n < 14
+                raise RuntimeError("EINVAL")
+    finally:
+        m.set_profiling(0)
+        m.set_precision("f32")
