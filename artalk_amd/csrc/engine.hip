@@ -98,6 +98,7 @@ struct SiteExps {
     struct AR { int ln1, attn, ln2, ffn; } ar[32];
     struct VAE { int ln, qkv, attn, resid, mlp; } vae[2][16];
     int vae_enc_in, vae_dec_in, vae_dec_head;
+    int style_in; struct ST { int h, attn, h1, ffn; } style[8];      // style encoder: fp32 A rows split while staging
     SiteExps() { int* p = reinterpret_cast<int*>(this); for (size_t i = 0; i < sizeof(SiteExps) / sizeof(int); ++i) p[i] = kActExp; }
 };
 
@@ -712,11 +713,15 @@ void run_style(artalk_model* m, const float* style_motion, int B, hipStream_t s,
     kbucket(m, KB_STYLE);
     if (style_motion && encode) {
         launch_style_input(style_motion, m->st_mean, m->st_std, w.s_in, B, s);
-        linear(m, w.s_in, 128, m->st_proj_w, m->st_proj_b, w.s_h, S, M, S, 128, ACT_NONE, nullptr, s);
+        SiteExps& ex = m->ex;
+        audit(m, "style.input(fp32 A)", -1, nullptr, w.s_in, M, 128, 128, false, s, &ex.style_in);
+        linear(m, w.s_in, 128, m->st_proj_w, m->st_proj_b, w.s_h, S, M, S, 128, ACT_NONE, nullptr, s, 0, nullptr, ex.style_in);
         launch_add_row(w.s_h, m->st_pe, M, S, s);   // PositionalEncoding quirk: pe[:, seq_len] added to every token
         for (int i = 0; i < c.style_layers; ++i) {
             const StyleLayer& Ly = m->style[i];
-            linear(m, w.s_h, S, Ly.in_w, Ly.in_b, w.s_qkv, 3 * S, M, 3 * S, S, ACT_NONE, nullptr, s);
+            SiteExps::ST& E = ex.style[i];
+            audit(m, "style.layer", i, ".in(fp32 A)", w.s_h, M, S, S, false, s, &E.h);
+            linear(m, w.s_h, S, Ly.in_w, Ly.in_b, w.s_qkv, 3 * S, M, 3 * S, S, ACT_NONE, nullptr, s, 0, nullptr, E.h);
             AttnArgs a;
             a.Q = w.s_qkv; a.K = w.s_qkv + S; a.V = w.s_qkv + 2 * S; a.ldq = a.ldk = a.ldv = 3 * S;
             a.q_bstride = a.k_bstride = a.v_bstride = (long)L * 3 * S;
@@ -724,10 +729,13 @@ void run_style(artalk_model* m, const float* style_motion, int B, hipStream_t s,
             a.B = B; a.H = c.style_heads; a.HD = S / c.style_heads; a.Lq = L; a.Lk = L;
             a.scale = 1.0f / std::sqrt((float)(S / c.style_heads));
             launch_attention(a, s);
-            linear(m, w.s_att, S, Ly.out_w, Ly.out_b, w.s_tmp, S, M, S, S, ACT_NONE, w.s_h, s);
+            audit(m, "style.layer", i, ".attn_out(fp32 A)", w.s_att, M, S, S, false, s, &E.attn);
+            linear(m, w.s_att, S, Ly.out_w, Ly.out_b, w.s_tmp, S, M, S, S, ACT_NONE, w.s_h, s, 0, nullptr, E.attn);
             layernorm(w.s_tmp, w.s_h, Ly.n1w, Ly.n1b, M, S, 1e-5f, ACT_NONE, s);
-            linear(m, w.s_h, S, Ly.l1_w, Ly.l1_b, w.s_ffn, c.style_ffn, M, c.style_ffn, S, ACT_GELU_ERF, nullptr, s);
-            linear(m, w.s_ffn, c.style_ffn, Ly.l2_w, Ly.l2_b, w.s_tmp, S, M, S, c.style_ffn, ACT_NONE, w.s_h, s);
+            audit(m, "style.layer", i, ".norm1(fp32 A)", w.s_h, M, S, S, false, s, &E.h1);
+            linear(m, w.s_h, S, Ly.l1_w, Ly.l1_b, w.s_ffn, c.style_ffn, M, c.style_ffn, S, ACT_GELU_ERF, nullptr, s, 0, nullptr, E.h1);
+            audit(m, "style.layer", i, ".ffn_hidden(fp32 A)", w.s_ffn, M, c.style_ffn, c.style_ffn, false, s, &E.ffn);
+            linear(m, w.s_ffn, c.style_ffn, Ly.l2_w, Ly.l2_b, w.s_tmp, S, M, S, c.style_ffn, ACT_NONE, w.s_h, s, 0, nullptr, E.ffn);
             layernorm(w.s_tmp, w.s_h, Ly.n2w, Ly.n2b, M, S, 1e-5f, ACT_NONE, s);
         }
     }
@@ -1214,7 +1222,7 @@ int artalk_create(int device_id, const artalk_config* cfg, artalk_model** out) {
               c.w2v_conv_dim == 512 && c.w2v_n_conv >= 2 && c.w2v_n_conv <= 8 && c.ar_heads * 64 == kE && c.vae_heads * 64 == c.vae_hidden &&
               c.w2v_heads * 64 == c.w2v_hidden && c.style_dim == 128 && c.style_heads * 32 == c.style_dim && c.style_len == 50 &&
               c.w2v_conv_kernel[0] == 10 && c.w2v_conv_stride[0] == 5 && c.w2v_ffn % 32 == 0 && c.style_ffn % 32 == 0 &&
-              c.w2v_layers >= 1 && c.w2v_layers <= 64 && c.ar_depth >= 1 && c.ar_depth <= 32 && c.vae_depth >= 1 && c.vae_depth <= 16;      // (SiteExps tables)
+              c.w2v_layers >= 1 && c.w2v_layers <= 64 && c.ar_depth >= 1 && c.ar_depth <= 32 && c.vae_depth >= 1 && c.vae_depth <= 16 && c.style_layers >= 1 && c.style_layers <= 8;      // (SiteExps tables)
     for (int i = 0; ok && i < 5; ++i) ok = c.patch_nums[i] == want_pn[i];
     if (!ok) { g_create_error = "unsupported configuration (kernels are specialised for assets/config.json + XLS-R-300M widths)"; return ARTALK_EINVAL; }
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return ARTALK_EHIP; }
