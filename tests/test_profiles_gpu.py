@@ -136,6 +136,47 @@ def test_calibration_leaves_in_range_profiles_untouched():
             m.set_precision("f32")
 
 
+def test_heavy_calibration_generalises_to_other_clips():
+    """The scales calibrated on ONE clip of the `heavy` profile (headroom 4) hold for clips the calibration never saw: a ragged batch of six
+    other clips (two with style) runs in f16x3 mode with a clean status word, and agrees with the exact-f32 mode of the same library
+    (itself pinned to the reference on this profile by the goldens above): decisions identical up to the first rounding-level flip of a
+    clip (at most one clip may have one), FLAME codes of the decision-exact chunks within 1e-5."""
+    from artalk_amd.synth import synth_audio, synth_style
+    g = load_golden("heavy_full_4s_s2")
+    m = get_gpu_model("full", "heavy")
+    cfg, sd = get_state_dict("full", "heavy")
+    audio, style = golden_inputs(g, sd)
+    mean, std = sd["basic_vae.motion_mean"].numpy(), sd["basic_vae.motion_std"].numpy()
+    secs = [10.0, 6.3, 4.0, 9.1, 2.2, 12.0]
+    audios = [torch.from_numpy(synth_audio(500 + i, t)) for i, t in enumerate(secs)]
+    styles = [None, torch.from_numpy(synth_style(51, mean, std)), None, None, torch.from_numpy(synth_style(54, mean, std)), None]
+    try:
+        m.reset_scales()
+        m.set_precision("f16x3")
+        assert m.calibrate([audio], [style]) > 0
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            fast = m.inference_batch(audios, styles, return_aux=True)
+        fbits = [b.cpu().numpy() for b in m.last_aux["bits"]]
+        assert not w and m._precision == "f16x3" and m.status() == 0, "an unseen clip left the calibrated range (headroom 4)"
+        m.set_precision("f32")
+        exact = m.inference_batch(audios, styles, return_aux=True)
+        ebits = [b.cpu().numpy() for b in m.last_aux["bits"]]
+        flipped, worst = 0, 0.0
+        for i in range(len(audios)):
+            nch = fbits[i].shape[0]
+            good = next((c for c in range(nch) if not np.array_equal(fbits[i][c], ebits[i][c])), nch)
+            flipped += good < nch
+            n = min(good * 100, fast[i].shape[0])
+            if n:
+                worst = max(worst, float((fast[i][:n] - exact[i][:n]).abs().max()))
+        assert flipped <= 1, f"{flipped} of {len(audios)} clips take another decision in f16x3 mode than in f32 mode"
+        assert worst < 1e-5, worst
+        print(f"heavy profile, 6 unseen clips after calibrating on one: status 0, clips with a decision flip {flipped}, FLAME max-abs diff to f32 mode {worst:.2e}")
+    finally:
+        m.set_precision("f32")
+
+
 def test_zz_drop_profile_models():
     """(housekeeping: frees the extra full-size models before later test files allocate theirs)"""
     for prof in ("outlier", "heavy"):
